@@ -1,0 +1,142 @@
+/*
+ * nbody_engine.h -- C ABI of the MI355X gravity engine (libnbody_engine.so).
+ *
+ * The reference program has no plugin or FFI interface; its seam is the body of the per-frame iteration
+ * in main.go:104-178: "given the live body set, advance it by dt" (direct O(N^2) loop main.go:105-128 or
+ * octree build + walk main.go:129-149, then body.update main.go:171-177).  Every entry point below
+ * replaces a piece of that iteration and says which.  A Go host binds them through cgo with flat
+ * []float64 / []uint64 slices (no Go pointers are retained after a call returns).
+ *
+ * Conventions: every function returns 0 on success or a negative NBE_E_* code; nbe_last_error() gives the
+ * message of the calling thread's last failure.  The reference panics on every error (main.go:213-238),
+ * so a host that wants identical behaviour turns a non-zero return into a panic.  The caller owns all host
+ * arrays; the library copies during the call.  One engine is driven by one thread at a time.  There is no
+ * CPU fallback: creation fails when no HIP device is usable.
+ */
+#ifndef NBODY_ENGINE_H
+#define NBODY_ENGINE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct nbe_engine nbe_engine;
+
+enum { NBE_MODE_DIRECT = 0, NBE_MODE_TREE = 1 };
+/* NBE_PREC_F32: fp32 state and arithmetic.  NBE_PREC_MIXED: fp64 state and integrator, fp32 pair terms
+ * summed in fp32 per source tile and across tiles in fp64.  NBE_PREC_F64: fp64 throughout. */
+enum { NBE_PREC_F32 = 0, NBE_PREC_MIXED = 1, NBE_PREC_F64 = 2 };
+
+enum {
+    NBE_OK = 0,
+    NBE_E_INVALID = -1,     /* bad argument or call order */
+    NBE_E_DEVICE = -2,      /* HIP runtime error, or no device */
+    NBE_E_NOMEM = -3,
+    NBE_E_UNSUPPORTED = -4
+};
+
+/* Run-time form of the compile-time constants of main.go:28 (dt), :73 (theta), :74-76 (simbound) and
+ * physics.go:132 (G).  eps is Plummer softening added under the square root; 0 keeps the reference's
+ * unsoftened force (physics.go:136, tree.go:234). */
+typedef struct {
+    int mode;               /* NBE_MODE_*: the `-tree` flag, main.go:22 */
+    int precision;          /* NBE_PREC_* */
+    double G, theta, dt, eps;
+    double bound_center[3];
+    double bound_width;     /* edge of the cubic simulation bound; bodies outside are removed in tree mode */
+    int device;             /* HIP device ordinal */
+    int reserved;
+} nbe_config;
+
+typedef struct {
+    uint64_t n, n_alive;
+    uint64_t steps;             /* steps taken since upload */
+    uint64_t interactions;      /* force evaluations in the last force pass: direct = targets*(sources);
+                                   tree = accepted body-node and body-leaf evaluations (tree.go:232-238) */
+    uint64_t tree_nodes;        /* leaves + branching cells of the last build */
+    uint64_t tree_cells;        /* branching cells of the last build */
+    float ms_sort, ms_build, ms_force, ms_total;   /* device time of the last timed step (nbe_step_timed) */
+} nbe_stats_t;
+
+/* Raw device pointers of the engine's state for a host that exchanges shards itself (for example with
+ * RCCL through torch.distributed).  pos_mass and vel hold `n` elements of 4 reals (x,y,z,mass / vx,vy,vz,0);
+ * `elem_bytes` is 16 (fp32 state) or 32 (fp64 state).  *_next are the buffers nbe_shard_advance writes. */
+typedef struct {
+    void *pos_mass, *vel;
+    void *pos_mass_next, *vel_next;
+    uint64_t n;
+    uint32_t elem_bytes;
+    uint32_t reserved;
+} nbe_device_state_t;
+
+/* Fills cfg with the reference's constants: tree off, fp32, G = 6.67408e-11 (physics.go:132),
+ * theta = 1 (main.go:73), dt = 3600 (main.go:28), eps = 0, bound centre 0 width 2^16 (main.go:74-76). */
+int nbe_default_config(nbe_config *cfg);
+
+int nbe_create(const nbe_config *cfg, nbe_engine **out);
+void nbe_destroy(nbe_engine *e);
+
+/* Thread-local message of the last failing call. */
+const char *nbe_last_error(void);
+
+/* Replaces the body slice built by makebodies (physics.go:16-73) / overwriteBodies (main.go:243-248):
+ * n bodies as host structure-of-arrays, positions and velocities as xyzxyz...  `id` may be NULL
+ * (then id = index, as physics.go:37,69 assign).  All bodies start alive. */
+int nbe_upload(nbe_engine *e, size_t n, const double *pos_xyz, const double *vel_xyz, const double *mass,
+               const uint64_t *id);
+
+/* The copy of live bodies taken per frame at main.go:90-101.  Bodies removed by the tree bound check
+ * (tree.go:290-292) are left out, as the nil skip at main.go:91-95 does; survivors keep upload order.
+ * Any output pointer may be NULL.  *n_alive receives the number of bodies written. */
+int nbe_download(nbe_engine *e, double *pos_xyz, double *vel_xyz, double *mass, uint64_t *id, size_t *n_alive);
+
+/* Force pass only (main.go:105-149 without the update loop): accelerations f/m of all n uploaded bodies
+ * in upload order, xyzxyz...; removed bodies get 0.  `alive_out` (n bytes) may be NULL. */
+int nbe_accel(nbe_engine *e, double *acc_xyz, uint8_t *alive_out);
+
+/* nsteps iterations of main.go:104-178: force pass, then v += f/m*dt; x += v*dt (physics.go:101-115)
+ * fused into the force kernel's epilogue.  Asynchronous on the engine's stream. */
+int nbe_step(nbe_engine *e, int nsteps);
+
+/* One step bracketed by device events; fills stats->ms_* (synchronises). */
+int nbe_step_timed(nbe_engine *e, nbe_stats_t *stats);
+
+int nbe_sync(nbe_engine *e);
+int nbe_stats(nbe_engine *e, nbe_stats_t *stats);
+
+/* Total kinetic energy, potential energy (fp64 pair sum, softened by eps) and linear momentum of the
+ * live bodies; used for drift checks.  No counterpart in the reference (its only validation is the
+ * rendered frames). */
+int nbe_energy(nbe_engine *e, double *kinetic, double *potential, double momentum[3]);
+
+/* ---- sharded stepping (one engine per GPU, every engine holds all n bodies as sources) ----
+ * The reference's only data-parallel strategy is to give each of 4 goroutines a contiguous quarter of the
+ * bodies against a shared read-only tree (main.go:134-149); a shard is that quarter.
+ *   nbe_set_shard(first, count)   targets [first, first+count) in device order belong to this engine
+ *   nbe_shard_prepare             tree mode: sort by Morton key, reorder state, build the tree (replicated)
+ *   nbe_shard_advance             forces on the shard + fused update, written into *_next at the same indices
+ *   (caller all-gathers pos_mass_next and vel_next across engines)
+ *   nbe_shard_commit              *_next become current
+ * nbe_step is prepare + advance over all bodies + commit. */
+int nbe_set_shard(nbe_engine *e, uint64_t first, uint64_t count);
+int nbe_shard_prepare(nbe_engine *e);
+int nbe_shard_advance(nbe_engine *e);
+int nbe_shard_commit(nbe_engine *e);
+int nbe_device_state(nbe_engine *e, nbe_device_state_t *out);
+
+/* Run the engine's work on a caller-owned hipStream_t (NULL restores the engine's own stream). */
+int nbe_set_stream(nbe_engine *e, void *hip_stream);
+
+/* ---- dominant-kernel timing for benchmarks ----
+ * Runs `reps` back-to-back launches of the force kernel of the current mode on the current state without
+ * integrating, brackets them with HIP events on the engine's stream and returns the mean milliseconds
+ * per launch. */
+int nbe_time_force_kernel(nbe_engine *e, int reps, float *ms_per_launch);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NBODY_ENGINE_H */

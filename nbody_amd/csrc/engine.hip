@@ -1,0 +1,445 @@
+// C ABI of the gravity engine (see include/nbody_engine.h): engine lifetime, state upload/download and the
+// step driver that strings the sort, build and force kernels together on one HIP stream.
+#include "engine_internal.h"
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstring>
+#include <new>
+#include <vector>
+
+static thread_local char g_err[512] = "";
+
+void nbe_set_error(const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* nbe_last_error(void) { return g_err; }
+
+extern "C" int nbe_default_config(nbe_config* cfg)
+{
+    if (!cfg) { nbe_set_error("cfg is NULL"); return NBE_E_INVALID; }
+    memset(cfg, 0, sizeof(*cfg));
+    cfg->mode = NBE_MODE_DIRECT;
+    cfg->precision = NBE_PREC_F32;
+    cfg->G = 6.67408e-11;      // physics.go:132
+    cfg->theta = 1.0;          // main.go:73
+    cfg->dt = 3600.0;          // main.go:28
+    cfg->eps = 0.0;
+    cfg->bound_width = 65536.0;   // main.go:74-76
+    cfg->device = 0;
+    return NBE_OK;
+}
+
+static int use_device(nbe_engine* e)
+{
+    NBE_HIP(hipSetDevice(e->cfg.device));
+    return NBE_OK;
+}
+
+static int free_state(nbe_engine* e)
+{
+    void** ptrs[] = {&e->posm[0], &e->posm[1], &e->vel[0], &e->vel[1], (void**)&e->mirror[0], (void**)&e->mirror[1],
+                     (void**)&e->orig[0], (void**)&e->orig[1], &e->acc, &e->partial};
+    for (void** p : ptrs)
+        if (*p) { NBE_HIP(hipFree(*p)); *p = nullptr; }
+    e->partial_len = 0;
+    delete[] e->ids;
+    e->ids = nullptr;
+    e->n = 0;
+    return NBE_OK;
+}
+
+extern "C" int nbe_create(const nbe_config* cfg, nbe_engine** out)
+{
+    if (!cfg || !out) { nbe_set_error("nbe_create: NULL argument"); return NBE_E_INVALID; }
+    *out = nullptr;
+    if (cfg->mode != NBE_MODE_DIRECT && cfg->mode != NBE_MODE_TREE) { nbe_set_error("bad mode %d", cfg->mode); return NBE_E_INVALID; }
+    if (cfg->precision < NBE_PREC_F32 || cfg->precision > NBE_PREC_F64) { nbe_set_error("bad precision %d", cfg->precision); return NBE_E_INVALID; }
+    if (!(cfg->bound_width > 0) || !(cfg->theta >= 0) || !(cfg->eps >= 0)) { nbe_set_error("bound_width must be > 0, theta and eps >= 0"); return NBE_E_INVALID; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        nbe_set_error("no HIP device available (this library has no CPU path)");
+        return NBE_E_DEVICE;
+    }
+    if (cfg->device < 0 || cfg->device >= ndev) { nbe_set_error("device %d out of range (have %d)", cfg->device, ndev); return NBE_E_INVALID; }
+    nbe_engine* e = new (std::nothrow) nbe_engine();
+    if (!e) { nbe_set_error("out of host memory"); return NBE_E_NOMEM; }
+    e->cfg = *cfg;
+    e->state64 = cfg->precision != NBE_PREC_F32;
+    e->force64 = cfg->precision == NBE_PREC_F64;
+    e->elem = e->state64 ? 32 : 16;
+    int rc = use_device(e);
+    if (rc == NBE_OK && hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking) != hipSuccess) {
+        nbe_set_error("hipStreamCreate failed");
+        rc = NBE_E_DEVICE;
+    }
+    for (int k = 0; k < 4 && rc == NBE_OK; k++)
+        if (hipEventCreate(&e->ev[k]) != hipSuccess) { nbe_set_error("hipEventCreate failed"); rc = NBE_E_DEVICE; }
+    if (rc != NBE_OK) { delete e; return rc; }
+    e->stream = e->own_stream;
+    *out = e;
+    return NBE_OK;
+}
+
+extern "C" void nbe_destroy(nbe_engine* e)
+{
+    if (!e) return;
+    (void)hipSetDevice(e->cfg.device);
+    (void)hipStreamSynchronize(e->stream);
+    (void)free_state(e);
+    TreeWork& w = e->tw;
+    void* ptrs[] = {w.keys[0], w.keys[1], w.sidx[0], w.sidx[1], w.block_hist, w.scan_tmp, w.bt_first, w.bt_last, w.bt_parent,
+                    w.bt_level, w.lvlmask, w.cellcnt, w.nodes, w.node_level, w.node_sum, w.counters, w.d_interactions,
+                    e->d_energy};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    for (int k = 0; k < 4; k++)
+        if (e->ev[k]) (void)hipEventDestroy(e->ev[k]);
+    if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
+    delete e;
+}
+
+extern "C" int nbe_set_stream(nbe_engine* e, void* hip_stream)
+{
+    if (!e) { nbe_set_error("engine is NULL"); return NBE_E_INVALID; }
+    NBE_TRY(use_device(e));
+    NBE_HIP(hipStreamSynchronize(e->stream));
+    e->stream = hip_stream ? (hipStream_t)hip_stream : e->own_stream;
+    return NBE_OK;
+}
+
+extern "C" int nbe_upload(nbe_engine* e, size_t n, const double* pos, const double* vel, const double* mass, const uint64_t* id)
+{
+    if (!e) { nbe_set_error("engine is NULL"); return NBE_E_INVALID; }
+    if (n > 0 && (!pos || !vel || !mass)) { nbe_set_error("nbe_upload: NULL array"); return NBE_E_INVALID; }
+    if (n > 0x7fffffffull) { nbe_set_error("at most 2^31-1 bodies"); return NBE_E_UNSUPPORTED; }
+    NBE_TRY(use_device(e));
+    NBE_HIP(hipStreamSynchronize(e->stream));
+    NBE_TRY(free_state(e));
+    e->n = n;
+    e->cur = 0; e->orig_cur = 0;
+    e->prepared = false; e->advance_pending = false; e->have_counts = false;
+    e->shard_set = false; e->shard_first = 0; e->shard_count = n;
+    memset(&e->stats, 0, sizeof(e->stats));
+    e->stats.n = n; e->stats.n_alive = n;
+    e->host_nalive = n;
+    const size_t cap = n > 0 ? n : 1;
+    for (int b = 0; b < 2; b++) {
+        NBE_HIP(hipMalloc(&e->posm[b], cap * e->elem));
+        NBE_HIP(hipMalloc(&e->vel[b], cap * e->elem));
+        NBE_HIP(hipMalloc((void**)&e->orig[b], cap * 4));
+        if (e->cfg.precision == NBE_PREC_MIXED) NBE_HIP(hipMalloc((void**)&e->mirror[b], cap * sizeof(float4)));
+    }
+    NBE_HIP(hipMalloc(&e->acc, cap * e->elem));
+    e->ids = new (std::nothrow) uint64_t[cap];
+    if (!e->ids) { nbe_set_error("out of host memory"); return NBE_E_NOMEM; }
+    for (size_t i = 0; i < n; i++) e->ids[i] = id ? id[i] : (uint64_t)i;
+    if (n == 0) return NBE_OK;
+
+    std::vector<uint32_t> ident(n);
+    for (size_t i = 0; i < n; i++) ident[i] = (uint32_t)i;
+    if (e->state64) {
+        std::vector<double> hp(4 * n), hv(4 * n);
+        for (size_t i = 0; i < n; i++) {
+            hp[4 * i] = pos[3 * i]; hp[4 * i + 1] = pos[3 * i + 1]; hp[4 * i + 2] = pos[3 * i + 2]; hp[4 * i + 3] = mass[i];
+            hv[4 * i] = vel[3 * i]; hv[4 * i + 1] = vel[3 * i + 1]; hv[4 * i + 2] = vel[3 * i + 2]; hv[4 * i + 3] = 0.0;
+        }
+        NBE_HIP(hipMemcpy(e->posm[0], hp.data(), n * 32, hipMemcpyHostToDevice));
+        NBE_HIP(hipMemcpy(e->vel[0], hv.data(), n * 32, hipMemcpyHostToDevice));
+        if (e->cfg.precision == NBE_PREC_MIXED) {
+            std::vector<float> hm(4 * n);
+            for (size_t i = 0; i < 4 * n; i++) hm[i] = (float)hp[i];
+            NBE_HIP(hipMemcpy(e->mirror[0], hm.data(), n * 16, hipMemcpyHostToDevice));
+        }
+    } else {
+        std::vector<float> hp(4 * n), hv(4 * n);
+        for (size_t i = 0; i < n; i++) {
+            hp[4 * i] = (float)pos[3 * i]; hp[4 * i + 1] = (float)pos[3 * i + 1]; hp[4 * i + 2] = (float)pos[3 * i + 2];
+            hp[4 * i + 3] = (float)mass[i];
+            hv[4 * i] = (float)vel[3 * i]; hv[4 * i + 1] = (float)vel[3 * i + 1]; hv[4 * i + 2] = (float)vel[3 * i + 2];
+            hv[4 * i + 3] = 0.0f;
+        }
+        NBE_HIP(hipMemcpy(e->posm[0], hp.data(), n * 16, hipMemcpyHostToDevice));
+        NBE_HIP(hipMemcpy(e->vel[0], hv.data(), n * 16, hipMemcpyHostToDevice));
+    }
+    NBE_HIP(hipMemcpy(e->orig[0], ident.data(), n * 4, hipMemcpyHostToDevice));
+    NBE_HIP(hipMemcpy(e->orig[1], ident.data(), n * 4, hipMemcpyHostToDevice));
+    if (e->cfg.mode == NBE_MODE_TREE) NBE_TRY(tree_workspace_reserve(e));
+    return NBE_OK;
+}
+
+// Number of live bodies: n until a tree build has removed some (device order keeps them at the tail).
+static int read_counts(nbe_engine* e, size_t* n_alive)
+{
+    *n_alive = e->n;
+    if (e->have_counts && e->n > 0) {
+        int c[4];
+        NBE_HIP(hipMemcpyAsync(c, e->tw.counters, sizeof(c), hipMemcpyDeviceToHost, e->stream));
+        NBE_HIP(hipStreamSynchronize(e->stream));
+        *n_alive = (size_t)c[0];
+        e->stats.tree_nodes = (uint64_t)c[1];
+        e->stats.tree_cells = (uint64_t)c[2];
+    }
+    e->host_nalive = *n_alive;
+    e->stats.n_alive = *n_alive;
+    return NBE_OK;
+}
+
+extern "C" int nbe_download(nbe_engine* e, double* pos, double* vel, double* mass, uint64_t* id, size_t* n_alive_out)
+{
+    if (!e) { nbe_set_error("engine is NULL"); return NBE_E_INVALID; }
+    NBE_TRY(use_device(e));
+    if (e->advance_pending) { nbe_set_error("nbe_download between nbe_shard_advance and nbe_shard_commit"); return NBE_E_INVALID; }
+    const size_t n = e->n;
+    size_t na = 0;
+    NBE_TRY(read_counts(e, &na));
+    if (n_alive_out) *n_alive_out = na;
+    if (n == 0) return NBE_OK;
+    std::vector<uint32_t> horig(n);
+    NBE_HIP(hipMemcpyAsync(horig.data(), e->orig[e->orig_cur], n * 4, hipMemcpyDeviceToHost, e->stream));
+    std::vector<double> hp, hv;
+    std::vector<float> fp, fv;
+    if (e->state64) {
+        hp.resize(4 * n); hv.resize(4 * n);
+        NBE_HIP(hipMemcpyAsync(hp.data(), e->posm[e->cur], n * 32, hipMemcpyDeviceToHost, e->stream));
+        NBE_HIP(hipMemcpyAsync(hv.data(), e->vel[e->cur], n * 32, hipMemcpyDeviceToHost, e->stream));
+    } else {
+        fp.resize(4 * n); fv.resize(4 * n);
+        NBE_HIP(hipMemcpyAsync(fp.data(), e->posm[e->cur], n * 16, hipMemcpyDeviceToHost, e->stream));
+        NBE_HIP(hipMemcpyAsync(fv.data(), e->vel[e->cur], n * 16, hipMemcpyDeviceToHost, e->stream));
+    }
+    NBE_HIP(hipStreamSynchronize(e->stream));
+    // survivors (device index < na) in upload order
+    std::vector<uint32_t> slot_of(n, 0xffffffffu);   // upload index -> device index
+    for (size_t d = 0; d < na; d++) slot_of[horig[d]] = (uint32_t)d;
+    size_t k = 0;
+    for (size_t u = 0; u < n; u++) {
+        const uint32_t d = slot_of[u];
+        if (d == 0xffffffffu) continue;
+        for (int c = 0; c < 3; c++) {
+            if (pos) pos[3 * k + c] = e->state64 ? hp[4 * (size_t)d + c] : (double)fp[4 * (size_t)d + c];
+            if (vel) vel[3 * k + c] = e->state64 ? hv[4 * (size_t)d + c] : (double)fv[4 * (size_t)d + c];
+        }
+        if (mass) mass[k] = e->state64 ? hp[4 * (size_t)d + 3] : (double)fp[4 * (size_t)d + 3];
+        if (id) id[k] = e->ids[u];
+        k++;
+    }
+    return NBE_OK;
+}
+
+static int force_pass(nbe_engine* e, uint64_t t0, uint64_t t1, bool fused)
+{
+    if (e->cfg.mode == NBE_MODE_TREE) return tree_forces(e, e->cur, t0, t1, fused, e->cur ^ 1);
+    return direct_forces(e, e->cur, t0, t1, fused, e->cur ^ 1);
+}
+
+extern "C" int nbe_shard_prepare(nbe_engine* e)
+{
+    if (!e) { nbe_set_error("engine is NULL"); return NBE_E_INVALID; }
+    NBE_TRY(use_device(e));
+    if (e->advance_pending) { nbe_set_error("nbe_shard_prepare before nbe_shard_commit"); return NBE_E_INVALID; }
+    if (e->cfg.mode == NBE_MODE_TREE && !e->prepared) NBE_TRY(tree_sort_and_build(e));
+    e->prepared = true;
+    return NBE_OK;
+}
+
+extern "C" int nbe_shard_advance(nbe_engine* e)
+{
+    if (!e) { nbe_set_error("engine is NULL"); return NBE_E_INVALID; }
+    NBE_TRY(use_device(e));
+    if (!e->prepared) { nbe_set_error("nbe_shard_advance without nbe_shard_prepare"); return NBE_E_INVALID; }
+    if (e->advance_pending) { nbe_set_error("nbe_shard_advance called twice"); return NBE_E_INVALID; }
+    uint64_t t0 = e->shard_set ? e->shard_first : 0;
+    uint64_t t1 = e->shard_set ? e->shard_first + e->shard_count : e->n;
+    if (t1 > e->n) t1 = e->n;
+    if (t0 > t1) t0 = t1;
+    NBE_TRY(force_pass(e, t0, t1, true));
+    e->advance_pending = true;
+    return NBE_OK;
+}
+
+extern "C" int nbe_shard_commit(nbe_engine* e)
+{
+    if (!e) { nbe_set_error("engine is NULL"); return NBE_E_INVALID; }
+    if (!e->advance_pending) { nbe_set_error("nbe_shard_commit without nbe_shard_advance"); return NBE_E_INVALID; }
+    e->cur ^= 1;
+    e->advance_pending = false;
+    e->prepared = false;
+    e->stats.steps++;
+    return NBE_OK;
+}
+
+extern "C" int nbe_set_shard(nbe_engine* e, uint64_t first, uint64_t count)
+{
+    if (!e) { nbe_set_error("engine is NULL"); return NBE_E_INVALID; }
+    if (first > e->n || count > e->n - first) { nbe_set_error("shard [%llu, +%llu) outside 0..%zu", (unsigned long long)first, (unsigned long long)count, e->n); return NBE_E_INVALID; }
+    if (e->advance_pending) { nbe_set_error("nbe_set_shard between advance and commit"); return NBE_E_INVALID; }
+    e->shard_first = first;
+    e->shard_count = count;
+    e->shard_set = true;
+    return NBE_OK;
+}
+
+extern "C" int nbe_device_state(nbe_engine* e, nbe_device_state_t* out)
+{
+    if (!e || !out) { nbe_set_error("NULL argument"); return NBE_E_INVALID; }
+    out->pos_mass = e->posm[e->cur];
+    out->vel = e->vel[e->cur];
+    out->pos_mass_next = e->posm[e->cur ^ 1];
+    out->vel_next = e->vel[e->cur ^ 1];
+    out->n = e->n;
+    out->elem_bytes = (uint32_t)e->elem;
+    out->reserved = 0;
+    return NBE_OK;
+}
+
+static int step_once_full(nbe_engine* e)
+{
+    if (e->cfg.mode == NBE_MODE_TREE && !e->prepared) NBE_TRY(tree_sort_and_build(e));
+    else if (e->timing) {
+        NBE_HIP(hipEventRecord(e->ev[0], e->stream));
+        NBE_HIP(hipEventRecord(e->ev[1], e->stream));
+        NBE_HIP(hipEventRecord(e->ev[2], e->stream));
+    }
+    NBE_TRY(force_pass(e, 0, e->n, true));
+    if (e->timing) NBE_HIP(hipEventRecord(e->ev[3], e->stream));
+    e->cur ^= 1;
+    e->prepared = false;
+    e->stats.steps++;
+    return NBE_OK;
+}
+
+extern "C" int nbe_step(nbe_engine* e, int nsteps)
+{
+    if (!e) { nbe_set_error("engine is NULL"); return NBE_E_INVALID; }
+    if (nsteps < 0) { nbe_set_error("nsteps < 0"); return NBE_E_INVALID; }
+    NBE_TRY(use_device(e));
+    if (e->advance_pending) { nbe_set_error("nbe_step between nbe_shard_advance and nbe_shard_commit"); return NBE_E_INVALID; }
+    if (e->shard_set && (e->shard_first != 0 || e->shard_count != e->n)) {
+        nbe_set_error("nbe_step on an engine with a partial shard; use the nbe_shard_* calls");
+        return NBE_E_INVALID;
+    }
+    if (e->n == 0) return NBE_OK;
+    for (int s = 0; s < nsteps; s++) NBE_TRY(step_once_full(e));
+    return NBE_OK;
+}
+
+static int fetch_interactions(nbe_engine* e)
+{
+    if (e->cfg.mode == NBE_MODE_TREE && e->tw.d_interactions) {
+        unsigned long long v = 0;
+        NBE_HIP(hipMemcpyAsync(&v, e->tw.d_interactions, sizeof(v), hipMemcpyDeviceToHost, e->stream));
+        NBE_HIP(hipStreamSynchronize(e->stream));
+        e->stats.interactions = v;
+    }
+    return NBE_OK;
+}
+
+extern "C" int nbe_step_timed(nbe_engine* e, nbe_stats_t* stats)
+{
+    if (!e) { nbe_set_error("engine is NULL"); return NBE_E_INVALID; }
+    NBE_TRY(use_device(e));
+    if (e->n == 0) { if (stats) *stats = e->stats; return NBE_OK; }
+    if (e->advance_pending || e->prepared) { nbe_set_error("nbe_step_timed inside a sharded step"); return NBE_E_INVALID; }
+    e->timing = true;
+    int rc = step_once_full(e);
+    e->timing = false;
+    NBE_TRY(rc);
+    NBE_HIP(hipEventSynchronize(e->ev[3]));
+    NBE_HIP(hipEventElapsedTime(&e->stats.ms_sort, e->ev[0], e->ev[1]));
+    NBE_HIP(hipEventElapsedTime(&e->stats.ms_build, e->ev[1], e->ev[2]));
+    NBE_HIP(hipEventElapsedTime(&e->stats.ms_force, e->ev[2], e->ev[3]));
+    NBE_HIP(hipEventElapsedTime(&e->stats.ms_total, e->ev[0], e->ev[3]));
+    NBE_TRY(fetch_interactions(e));
+    size_t na;
+    NBE_TRY(read_counts(e, &na));
+    if (stats) *stats = e->stats;
+    return NBE_OK;
+}
+
+extern "C" int nbe_sync(nbe_engine* e)
+{
+    if (!e) { nbe_set_error("engine is NULL"); return NBE_E_INVALID; }
+    NBE_TRY(use_device(e));
+    NBE_HIP(hipStreamSynchronize(e->stream));
+    return NBE_OK;
+}
+
+extern "C" int nbe_stats(nbe_engine* e, nbe_stats_t* stats)
+{
+    if (!e || !stats) { nbe_set_error("NULL argument"); return NBE_E_INVALID; }
+    NBE_TRY(use_device(e));
+    NBE_TRY(fetch_interactions(e));
+    size_t na;
+    NBE_TRY(read_counts(e, &na));
+    e->stats.n = e->n;
+    *stats = e->stats;
+    return NBE_OK;
+}
+
+extern "C" int nbe_accel(nbe_engine* e, double* acc_xyz, uint8_t* alive_out)
+{
+    if (!e) { nbe_set_error("engine is NULL"); return NBE_E_INVALID; }
+    NBE_TRY(use_device(e));
+    if (e->advance_pending) { nbe_set_error("nbe_accel between nbe_shard_advance and nbe_shard_commit"); return NBE_E_INVALID; }
+    const size_t n = e->n;
+    if (n == 0) return NBE_OK;
+    if (!acc_xyz) { nbe_set_error("acc_xyz is NULL"); return NBE_E_INVALID; }
+    NBE_HIP(hipMemsetAsync(e->acc, 0, n * e->elem, e->stream));
+    if (e->cfg.mode == NBE_MODE_TREE && !e->prepared) { NBE_TRY(tree_sort_and_build(e)); e->prepared = true; }
+    NBE_TRY(force_pass(e, 0, n, false));
+    std::vector<uint32_t> horig(n);
+    NBE_HIP(hipMemcpyAsync(horig.data(), e->orig[e->orig_cur], n * 4, hipMemcpyDeviceToHost, e->stream));
+    std::vector<double> ha;
+    std::vector<float> fa;
+    if (e->state64) { ha.resize(4 * n); NBE_HIP(hipMemcpyAsync(ha.data(), e->acc, n * 32, hipMemcpyDeviceToHost, e->stream)); }
+    else { fa.resize(4 * n); NBE_HIP(hipMemcpyAsync(fa.data(), e->acc, n * 16, hipMemcpyDeviceToHost, e->stream)); }
+    NBE_HIP(hipStreamSynchronize(e->stream));
+    NBE_TRY(fetch_interactions(e));
+    size_t na;
+    NBE_TRY(read_counts(e, &na));
+    for (size_t d = 0; d < n; d++) {
+        const size_t u = horig[d];
+        const bool live = d < na;
+        for (int c = 0; c < 3; c++)
+            acc_xyz[3 * u + c] = live ? (e->state64 ? ha[4 * d + c] : (double)fa[4 * d + c]) : 0.0;
+        if (alive_out) alive_out[u] = live ? 1 : 0;
+    }
+    return NBE_OK;
+}
+
+extern "C" int nbe_energy(nbe_engine* e, double* kinetic, double* potential, double momentum[3])
+{
+    if (!e) { nbe_set_error("engine is NULL"); return NBE_E_INVALID; }
+    NBE_TRY(use_device(e));
+    if (e->advance_pending) { nbe_set_error("nbe_energy between nbe_shard_advance and nbe_shard_commit"); return NBE_E_INVALID; }
+    if (e->n > 4u * 1024u * 1024u) { nbe_set_error("nbe_energy sums all pairs in fp64 and is limited to 4M bodies"); return NBE_E_UNSUPPORTED; }
+    return energy_compute(e, kinetic, potential, momentum);
+}
+
+extern "C" int nbe_time_force_kernel(nbe_engine* e, int reps, float* ms_per_launch)
+{
+    if (!e || !ms_per_launch || reps <= 0) { nbe_set_error("bad argument"); return NBE_E_INVALID; }
+    NBE_TRY(use_device(e));
+    if (e->advance_pending) { nbe_set_error("nbe_time_force_kernel inside a sharded step"); return NBE_E_INVALID; }
+    *ms_per_launch = 0;
+    if (e->n == 0) return NBE_OK;
+    if (e->cfg.mode == NBE_MODE_TREE && !e->prepared) { NBE_TRY(tree_sort_and_build(e)); e->prepared = true; }
+    uint64_t t0 = e->shard_set ? e->shard_first : 0;
+    uint64_t t1 = e->shard_set ? e->shard_first + e->shard_count : e->n;
+    NBE_TRY(force_pass(e, t0, t1, false));   // warm-up
+    NBE_HIP(hipEventRecord(e->ev[0], e->stream));
+    for (int r = 0; r < reps; r++) NBE_TRY(force_pass(e, t0, t1, false));
+    NBE_HIP(hipEventRecord(e->ev[3], e->stream));
+    NBE_HIP(hipEventSynchronize(e->ev[3]));
+    float ms = 0;
+    NBE_HIP(hipEventElapsedTime(&ms, e->ev[0], e->ev[3]));
+    *ms_per_launch = ms / (float)reps;
+    NBE_TRY(fetch_interactions(e));
+    return NBE_OK;
+}

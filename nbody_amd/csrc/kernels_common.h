@@ -1,0 +1,39 @@
+// Device helpers shared by the force kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+
+template <typename R> struct V4;
+template <> struct V4<float> { using type = float4; };
+template <> struct V4<double> { using type = double4; };
+
+__device__ __forceinline__ float rsq_dev(float x) { return __builtin_amdgcn_rsqf(x); }
+// v_rsq_f64 is an approximation; two Newton steps bring it to fp64 rounding level.
+__device__ __forceinline__ double rsq_dev(double x)
+{
+    double y = __builtin_amdgcn_rsq(x);
+    y = y * (1.5 - 0.5 * x * y * y);
+    y = y * (1.5 - 0.5 * x * y * y);
+    return y;
+}
+
+// What a force kernel does with a target's acceleration sum.
+enum { OUT_ACC = 0,       // store G*sum to the acceleration buffer
+       OUT_FUSED = 1,     // integrate the body (kick_drift) into the next-state buffers
+       OUT_PARTIAL = 2 }; // store the raw sum of one source range (direct sum only)
+
+// physics.go:101-115 for one body with a = f/m already formed: v += a*dt; x += v*dt.
+template <typename A>
+__device__ __forceinline__ void kick_drift(int i, A ax, A ay, A az, A dt,
+                                           const typename V4<A>::type* __restrict__ pos_in,
+                                           const typename V4<A>::type* __restrict__ vel_in,
+                                           typename V4<A>::type* __restrict__ pos_out,
+                                           typename V4<A>::type* __restrict__ vel_out,
+                                           float4* __restrict__ mirror_out)
+{
+    typename V4<A>::type p = pos_in[i], v = vel_in[i];
+    v.x += ax * dt; v.y += ay * dt; v.z += az * dt;
+    p.x += v.x * dt; p.y += v.y * dt; p.z += v.z * dt;
+    pos_out[i] = p;
+    vel_out[i] = v;
+    if (mirror_out) mirror_out[i] = make_float4((float)p.x, (float)p.y, (float)p.z, (float)p.w);
+}

@@ -1,0 +1,539 @@
+// GPU Barnes-Hut build: Morton keys -> LDS radix sort -> binary radix tree -> octree cells in depth-first
+// pre-order -> bottom-up mass / centre-of-mass reduction.
+//
+// Replaces maketree/push (tree.go:145-197, 284-295).  The reference inserts bodies one by one into a
+// pointer octree whose cells halve a fixed cube (octantBound tree.go:101-110) and picks the child by the
+// sign of p - centre per axis (octantBits tree.go:128-132: bit0 = X, bit1 = Y, bit2 = Z, ">= centre" is
+// the high half).  For a cube whose edge is a power of two that path is the sequence of 3-bit digits of
+// the body's 21-bit-per-axis fixed-point coordinates, so sorting bodies by the interleaved key puts them
+// in the order a depth-first walk with children 0..7 meets them, and every cell that holds two or more
+// bodies in different children ("branching cell") is a maximal run of keys sharing a 3L-bit prefix.
+// Chains of one-child cells, which the pointer tree keeps, are not materialised: they carry the same
+// mass and centre of mass as the branching cell below them and a larger edge, so the opening test
+// (tree.go:216-217) accepts the chain's top exactly when it accepts that cell, with the same force.
+// Deviations: depth is capped at 21 (cell edge = bound/2^21); bodies with identical keys become leaves of
+// one depth-21 cell (the reference would recurse without bound).  The centre of mass is the mass-weighted
+// mean, not the running update of tree.go:189-193.
+#include "engine_internal.h"
+
+#define SORT_KPT 8                     // keys per thread
+#define SORT_TILE (256 * SORT_KPT)     // keys per workgroup
+#define SCAN_TILE 2048                 // elements per workgroup in the device-wide scan (256 threads x 8)
+
+// ---- device-wide exclusive scan of uint32 -------------------------------------------------------------
+template <bool POPC>
+__device__ __forceinline__ uint32_t scan_load(const uint32_t* in, size_t i, size_t len)
+{
+    if (i >= len) return 0;
+    uint32_t v = in[i];
+    return POPC ? (uint32_t)__popc(v) : v;
+}
+
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
+{
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t t = __shfl_up(v, d, 64);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+
+// Exclusive scan of a 256-thread block's per-thread totals; returns this thread's offset, *total = block sum.
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* total)
+{
+    __shared__ uint32_t wsum[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t inc = wave_incl_scan(v);
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        uint32_t s = wsum[w];
+        if (w < wave) base += s;
+        tot += s;
+    }
+    __syncthreads();
+    *total = tot;
+    return base + inc - v;
+}
+
+template <bool POPC>
+__global__ __launch_bounds__(256) void scan_reduce_kernel(const uint32_t* __restrict__ in, size_t len,
+                                                          uint32_t* __restrict__ block_sums)
+{
+    const size_t base = (size_t)blockIdx.x * SCAN_TILE + (size_t)threadIdx.x * 8;
+    uint32_t s = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) s += scan_load<POPC>(in, base + k, len);
+    uint32_t tot;
+    block_excl_scan(s, &tot);
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
+}
+
+// One workgroup scans the block sums in place (exclusive).
+__global__ __launch_bounds__(256) void scan_sums_kernel(uint32_t* __restrict__ sums, int nsums)
+{
+    uint32_t carry = 0;
+    for (int base = 0; base < nsums; base += 256 * 8) {
+        uint32_t v[8], s = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            int i = base + threadIdx.x * 8 + k;
+            v[k] = i < nsums ? sums[i] : 0;
+            s += v[k];
+        }
+        uint32_t tot;
+        uint32_t off = carry + block_excl_scan(s, &tot);
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            int i = base + threadIdx.x * 8 + k;
+            if (i < nsums) sums[i] = off;
+            off += v[k];
+        }
+        carry += tot;
+    }
+}
+
+template <bool POPC>
+__global__ __launch_bounds__(256) void scan_apply_kernel(const uint32_t* __restrict__ in, size_t len,
+                                                         const uint32_t* __restrict__ block_offsets,
+                                                         uint32_t* __restrict__ out)
+{
+    const size_t base = (size_t)blockIdx.x * SCAN_TILE + (size_t)threadIdx.x * 8;
+    uint32_t v[8], s = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) { v[k] = scan_load<POPC>(in, base + k, len); s += v[k]; }
+    uint32_t tot;
+    uint32_t off = block_offsets[blockIdx.x] + block_excl_scan(s, &tot);
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        if (base + k < len) out[base + k] = off;
+        off += v[k];
+    }
+}
+
+template <bool POPC>
+static int device_exclusive_scan(nbe_engine* e, const uint32_t* in, uint32_t* out, size_t len)
+{
+    if (len == 0) return NBE_OK;
+    const unsigned nblk = cdiv(len, SCAN_TILE);
+    if (nblk > e->tw.scan_tmp_len) { nbe_set_error("scan workspace too small"); return NBE_E_INVALID; }
+    hipLaunchKernelGGL((scan_reduce_kernel<POPC>), dim3(nblk), dim3(256), 0, e->stream, in, len, e->tw.scan_tmp);
+    hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(256), 0, e->stream, e->tw.scan_tmp, (int)nblk);
+    hipLaunchKernelGGL((scan_apply_kernel<POPC>), dim3(nblk), dim3(256), 0, e->stream, in, len, e->tw.scan_tmp, out);
+    NBE_HIP(hipGetLastError());
+    return NBE_OK;
+}
+
+// ---- Morton keys ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t spread3(uint32_t v)   // 21 bits -> every third bit of 63
+{
+    uint64_t x = v & 0x1fffffull;
+    x = (x | x << 32) & 0x1f00000000ffffull;
+    x = (x | x << 16) & 0x1f0000ff0000ffull;
+    x = (x | x << 8) & 0x100f00f00f00f00full;
+    x = (x | x << 4) & 0x10c30c30c30c30c3ull;
+    x = (x | x << 2) & 0x1249249249249249ull;
+    return x;
+}
+
+#define KEY_DEAD 0xffffffffffffffffull
+
+// Index q in [0, 2^21) of the depth-21 cell with lo + q*cell <= x < lo + (q+1)*cell.  x - lo may round
+// across a cell boundary, so the estimate is corrected against the boundaries themselves, which are exact
+// for a power-of-two bound: the result then equals the chain of sign tests of octantBits (tree.go:128-132).
+__device__ __forceinline__ uint32_t cell_index(double x, double lo, double cell)
+{
+    double q = floor((x - lo) / cell);
+    q = fmin(fmax(q, 0.0), 2097151.0);
+    if (x < lo + q * cell && q > 0.0) q -= 1.0;
+    else if (x >= lo + (q + 1.0) * cell && q < 2097151.0) q += 1.0;
+    return (uint32_t)q;
+}
+
+// One key per body.  A body is kept iff lo <= p < hi on every axis (contains, tree.go:65-72; NaN fails);
+// others get the all-ones key, sort to the end and stay out of the tree for good (tree.go:290-292).
+template <typename R4>
+__global__ __launch_bounds__(256) void keys_kernel(const R4* __restrict__ posm, int n, double lox, double loy, double loz,
+                                                   double width, uint64_t* __restrict__ keys, uint32_t* __restrict__ idx,
+                                                   int* __restrict__ counters)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    int alive = 0;
+    if (i < n) {
+        R4 p = posm[i];
+        const double x = (double)p.x, y = (double)p.y, z = (double)p.z;
+        const bool in = (lox <= x && x < lox + width) && (loy <= y && y < loy + width) && (loz <= z && z < loz + width);
+        uint64_t key = KEY_DEAD;
+        if (in) {
+            const double cell = width * (1.0 / 2097152.0);    // 2^21 cells per axis at depth 21
+            key = spread3(cell_index(x, lox, cell)) | (spread3(cell_index(y, loy, cell)) << 1) |
+                  (spread3(cell_index(z, loz, cell)) << 2);
+            alive = 1;
+        }
+        keys[i] = key;
+        idx[i] = (uint32_t)i;
+    }
+    unsigned long long b = __ballot(alive);
+    if ((threadIdx.x & 63) == 0 && b) atomicAdd(&counters[0], (int)__popcll(b));
+}
+
+// ---- LSD radix sort, 8-bit digits, (key, index) pairs ---------------------------------------------------------
+__global__ __launch_bounds__(256) void radix_hist_kernel(const uint64_t* __restrict__ keys, int n, int shift, int nblocks,
+                                                         uint32_t* __restrict__ block_hist)
+{
+    __shared__ uint32_t h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const int base = blockIdx.x * SORT_TILE;
+#pragma unroll
+    for (int k = 0; k < SORT_KPT; k++) {
+        int i = base + k * 256 + threadIdx.x;
+        if (i < n) atomicAdd(&h[(uint32_t)(keys[i] >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    block_hist[(size_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
+}
+
+// Stable scatter.  Each wave owns a contiguous quarter of the tile and walks it 64 keys at a time; within a
+// round, lanes holding the same digit find each other with 8 ballots, and a per-wave digit counter in LDS
+// carries the running count across rounds.
+__global__ __launch_bounds__(256) void radix_scatter_kernel(const uint64_t* __restrict__ kin, const uint32_t* __restrict__ vin,
+                                                            uint64_t* __restrict__ kout, uint32_t* __restrict__ vout,
+                                                            const uint32_t* __restrict__ offsets, int n, int shift, int nblocks)
+{
+    __shared__ uint32_t wcount[4][256];
+    __shared__ uint32_t wbase[4][256];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int w = 0; w < 4; w++) wcount[w][tid] = 0;
+    __syncthreads();
+
+    volatile uint32_t* wc = wcount[wave];
+    const int base = blockIdx.x * SORT_TILE + wave * (SORT_TILE / 4);
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    uint64_t k[SORT_KPT];
+    uint32_t v[SORT_KPT], rank[SORT_KPT];
+#pragma unroll
+    for (int r = 0; r < SORT_KPT; r++) {
+        const int i = base + r * 64 + lane;
+        const bool valid = i < n;
+        k[r] = valid ? kin[i] : KEY_DEAD;
+        v[r] = valid ? vin[i] : 0u;
+        const uint32_t digit = (uint32_t)(k[r] >> shift) & 255u;
+        unsigned long long peers = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            const bool bit = (digit >> b) & 1u;
+            const unsigned long long m = __ballot(bit);
+            peers &= bit ? m : ~m;
+        }
+        uint32_t prior = 0;
+        if (valid) prior = wc[digit];
+        rank[r] = prior + (uint32_t)__popcll(peers & lt_mask);
+        if (valid && (peers & lt_mask) == 0) wc[digit] = prior + (uint32_t)__popcll(peers);
+    }
+    __syncthreads();
+    {
+        uint32_t run = 0;
+#pragma unroll
+        for (int w = 0; w < 4; w++) { wbase[w][tid] = run; run += wcount[w][tid]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < SORT_KPT; r++) {
+        const int i = base + r * 64 + lane;
+        if (i < n) {
+            const uint32_t digit = (uint32_t)(k[r] >> shift) & 255u;
+            const uint32_t pos = offsets[(size_t)digit * nblocks + blockIdx.x] + wbase[wave][digit] + rank[r];
+            kout[pos] = k[r];
+            vout[pos] = v[r];
+        }
+    }
+}
+
+// Reorders the state into sorted order (gather): dst[i] = src[idx[i]].
+template <typename S4>
+__global__ __launch_bounds__(256) void permute_kernel(const uint32_t* __restrict__ idx, int n, const S4* __restrict__ pos_in,
+                                                      const S4* __restrict__ vel_in, const uint32_t* __restrict__ orig_in,
+                                                      const float4* __restrict__ mirror_in, S4* __restrict__ pos_out,
+                                                      S4* __restrict__ vel_out, uint32_t* __restrict__ orig_out,
+                                                      float4* __restrict__ mirror_out)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t j = idx[i];
+    pos_out[i] = pos_in[j];
+    vel_out[i] = vel_in[j];
+    orig_out[i] = orig_in[j];
+    if (mirror_in) mirror_out[i] = mirror_in[j];
+}
+
+// ---- binary radix tree over the sorted keys ----------------------------------------------------------------
+// delta(i, j): length of the common prefix of keys i and j (keys occupy the low 63 bits), with the index as
+// tie-break for equal keys; -1 outside [0, na).
+__device__ __forceinline__ int key_delta(const uint64_t* __restrict__ keys, int na, int i, uint64_t ki, int j)
+{
+    if (j < 0 || j >= na) return -1;
+    const uint64_t kj = keys[j];
+    if (ki != kj) return __clzll((long long)(ki ^ kj)) - 1;
+    return 63 + __clz(i ^ j);
+}
+
+__device__ __forceinline__ int delta_level(int d) { int l = d / 3; return l > 21 ? 21 : l; }
+
+__global__ __launch_bounds__(256) void radix_tree_kernel(const uint64_t* __restrict__ keys, const int* __restrict__ counters,
+                                                         int* __restrict__ bt_first, int* __restrict__ bt_last,
+                                                         int* __restrict__ bt_parent, uint8_t* __restrict__ bt_level)
+{
+    const int na = counters[0];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= na - 1) return;
+    const uint64_t ki = keys[i];
+    const int dl = key_delta(keys, na, i, ki, i - 1), dr = key_delta(keys, na, i, ki, i + 1);
+    const int d = dr > dl ? 1 : -1;
+    const int dmin = dr > dl ? dl : dr;
+    int lmax = 2;
+    while (key_delta(keys, na, i, ki, i + lmax * d) > dmin) lmax <<= 1;
+    int l = 0;
+    for (int t = lmax >> 1; t >= 1; t >>= 1)
+        if (key_delta(keys, na, i, ki, i + (l + t) * d) > dmin) l += t;
+    const int j = i + l * d;
+    const int dnode = key_delta(keys, na, i, ki, j);
+    int s = 0;
+    int t = l;
+    do {
+        t = (t + 1) >> 1;
+        if (key_delta(keys, na, i, ki, i + (s + t) * d) > dnode) s += t;
+    } while (t > 1);
+    const int gamma = i + s * d + (d < 0 ? -1 : 0);
+    const int lo = i < j ? i : j, hi = i < j ? j : i;
+    bt_first[i] = lo;
+    bt_last[i] = hi;
+    bt_level[i] = (uint8_t)delta_level(dnode);
+    if (i == 0) bt_parent[0] = -1;
+    if (lo != gamma) bt_parent[gamma] = i;           // left child is internal node gamma
+    if (hi != gamma + 1) bt_parent[gamma + 1] = i;   // right child is internal node gamma+1
+}
+
+// A binary node is an octree branching cell iff its depth differs from its parent's.
+__global__ __launch_bounds__(256) void mark_cells_kernel(const int* __restrict__ counters, const int* __restrict__ bt_first,
+                                                         const int* __restrict__ bt_parent, const uint8_t* __restrict__ bt_level,
+                                                         uint32_t* __restrict__ lvlmask)
+{
+    const int na = counters[0];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= na - 1) return;
+    const int par = bt_parent[i];
+    const int lvl = bt_level[i];
+    if (par < 0 || bt_level[par] != lvl) atomicOr(&lvlmask[bt_first[i]], 1u << lvl);
+}
+
+template <typename NodeT> __device__ __forceinline__ void set_edge(NodeT& nd, double w);
+template <> __device__ __forceinline__ void set_edge<NodeF>(NodeF& nd, double w) { nd.w2 = (float)(w * w); }
+template <> __device__ __forceinline__ void set_edge<NodeD>(NodeD& nd, double w) { nd.w = w; }
+
+// Writes the pre-order node array: thread t < n handles sorted leaf t, thread n + i handles binary node i.
+// cellcnt[a] = number of branching cells whose first leaf is < a (exclusive scan of popcount(lvlmask)).
+template <typename R4, typename NodeT>
+__global__ __launch_bounds__(256) void emit_nodes_kernel(int n, int* __restrict__ counters, const R4* __restrict__ posm,
+                                                         const int* __restrict__ bt_first, const int* __restrict__ bt_last,
+                                                         const int* __restrict__ bt_parent, const uint8_t* __restrict__ bt_level,
+                                                         const uint32_t* __restrict__ lvlmask, const uint32_t* __restrict__ cellcnt,
+                                                         double bound_width, NodeT* __restrict__ nodes,
+                                                         uint8_t* __restrict__ node_level, double* __restrict__ node_sum)
+{
+    const int na = counters[0];
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t == 0) {
+        const int cells = na > 0 ? (int)cellcnt[na] : 0;
+        counters[1] = na + cells;
+        counters[2] = cells;
+    }
+    if (t < n) {
+        if (t >= na) return;
+        const int pos = t + (int)cellcnt[t + 1];
+        const R4 p = posm[t];
+        NodeT nd;
+        nd.x = p.x; nd.y = p.y; nd.z = p.z; nd.m = p.w;
+        set_edge<NodeT>(nd, 0.0);
+        nd.skip = pos + 1;
+        nodes[pos] = nd;
+        node_level[pos] = 255;
+        const double m = (double)p.w;
+        node_sum[4 * (size_t)pos + 0] = m;
+        node_sum[4 * (size_t)pos + 1] = m * (double)p.x;
+        node_sum[4 * (size_t)pos + 2] = m * (double)p.y;
+        node_sum[4 * (size_t)pos + 3] = m * (double)p.z;
+        return;
+    }
+    const int i = t - n;
+    if (i >= na - 1) return;
+    const int par = bt_parent[i];
+    const int lvl = bt_level[i];
+    if (!(par < 0 || bt_level[par] != lvl)) return;
+    const int a = bt_first[i], b = bt_last[i];
+    const int pos = a + (int)cellcnt[a] + __popc(lvlmask[a] & ((1u << lvl) - 1u));
+    NodeT nd;
+    nd.x = 0; nd.y = 0; nd.z = 0; nd.m = 0;
+    set_edge<NodeT>(nd, bound_width * (1.0 / (double)(1u << lvl)));   // exact: halving a power of two
+    nd.skip = (b + 1) + (int)cellcnt[b + 1];
+    nodes[pos] = nd;
+    node_level[pos] = (uint8_t)lvl;
+}
+
+// One depth per launch, deepest first: a cell sums its children (already final) in pre-order, which is the
+// octant order.  Totals are kept in fp64 beside the node array; the node gets mass and sum/mass.
+template <typename NodeT>
+__global__ __launch_bounds__(256) void cell_mass_kernel(const int* __restrict__ counters, int level, NodeT* __restrict__ nodes,
+                                                        const uint8_t* __restrict__ node_level, double* __restrict__ node_sum)
+{
+    const int total = counters[1];
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= total) return;
+    if (node_level[p] != level) return;
+    const int end = nodes[p].skip;
+    double m = 0, sx = 0, sy = 0, sz = 0;
+    for (int c = p + 1; c < end; c = nodes[c].skip) {
+        m += node_sum[4 * (size_t)c + 0];
+        sx += node_sum[4 * (size_t)c + 1];
+        sy += node_sum[4 * (size_t)c + 2];
+        sz += node_sum[4 * (size_t)c + 3];
+    }
+    node_sum[4 * (size_t)p + 0] = m;
+    node_sum[4 * (size_t)p + 1] = sx;
+    node_sum[4 * (size_t)p + 2] = sy;
+    node_sum[4 * (size_t)p + 3] = sz;
+    const double inv = m != 0.0 ? 1.0 / m : 0.0;
+    nodes[p].x = sx * inv;
+    nodes[p].y = sy * inv;
+    nodes[p].z = sz * inv;
+    nodes[p].m = m;
+}
+
+// ---- host side ---------------------------------------------------------------------------------------------
+static int free_ptr(void** p)
+{
+    if (*p) { NBE_HIP(hipFree(*p)); *p = nullptr; }
+    return NBE_OK;
+}
+
+int tree_workspace_reserve(nbe_engine* e)
+{
+    TreeWork& w = e->tw;
+    const size_t n = e->n;
+    if (w.cap >= n && w.cap > 0) return NBE_OK;
+    void** ptrs[] = {(void**)&w.keys[0], (void**)&w.keys[1], (void**)&w.sidx[0], (void**)&w.sidx[1], (void**)&w.block_hist,
+                     (void**)&w.scan_tmp, (void**)&w.bt_first, (void**)&w.bt_last, (void**)&w.bt_parent, (void**)&w.bt_level,
+                     (void**)&w.lvlmask, (void**)&w.cellcnt, (void**)&w.nodes, (void**)&w.node_level, (void**)&w.node_sum,
+                     (void**)&w.counters, (void**)&w.d_interactions};
+    for (void** p : ptrs) NBE_TRY(free_ptr(p));
+    const size_t cap = n > 0 ? n : 1;
+    const size_t nblocks = cdiv(cap, SORT_TILE);
+    w.block_hist_len = 256 * nblocks;
+    size_t scan_len = w.block_hist_len > cap + 1 ? w.block_hist_len : cap + 1;
+    w.scan_tmp_len = cdiv(scan_len, SCAN_TILE) + 1;
+    const size_t node_bytes = e->force64 ? sizeof(NodeD) : sizeof(NodeF);
+    NBE_HIP(hipMalloc((void**)&w.keys[0], cap * 8));
+    NBE_HIP(hipMalloc((void**)&w.keys[1], cap * 8));
+    NBE_HIP(hipMalloc((void**)&w.sidx[0], cap * 4));
+    NBE_HIP(hipMalloc((void**)&w.sidx[1], cap * 4));
+    NBE_HIP(hipMalloc((void**)&w.block_hist, w.block_hist_len * 4));
+    NBE_HIP(hipMalloc((void**)&w.scan_tmp, w.scan_tmp_len * 4));
+    NBE_HIP(hipMalloc((void**)&w.bt_first, cap * 4));
+    NBE_HIP(hipMalloc((void**)&w.bt_last, cap * 4));
+    NBE_HIP(hipMalloc((void**)&w.bt_parent, cap * 4));
+    NBE_HIP(hipMalloc((void**)&w.bt_level, cap));
+    NBE_HIP(hipMalloc((void**)&w.lvlmask, (cap + 1) * 4));
+    NBE_HIP(hipMalloc((void**)&w.cellcnt, (cap + 1) * 4));
+    NBE_HIP(hipMalloc((void**)&w.nodes, 2 * cap * node_bytes));
+    NBE_HIP(hipMalloc((void**)&w.node_level, 2 * cap));
+    NBE_HIP(hipMalloc((void**)&w.node_sum, 2 * cap * 4 * sizeof(double)));
+    NBE_HIP(hipMalloc((void**)&w.counters, 16 * sizeof(int)));
+    NBE_HIP(hipMalloc((void**)&w.d_interactions, sizeof(unsigned long long)));
+    NBE_HIP(hipMemsetAsync(w.counters, 0, 16 * sizeof(int), e->stream));
+    NBE_HIP(hipMemsetAsync(w.d_interactions, 0, sizeof(unsigned long long), e->stream));
+    w.cap = cap;
+    return NBE_OK;
+}
+
+template <typename R4, typename S4, typename NodeT>
+static int sort_and_build_t(nbe_engine* e)
+{
+    TreeWork& w = e->tw;
+    const int n = (int)e->n;
+    const int cur = e->cur, nxt = cur ^ 1;
+    const unsigned nb = cdiv(n, 256);
+    const bool mixed = e->cfg.precision == NBE_PREC_MIXED;
+    const R4* force_pos = mixed ? (const R4*)e->mirror[cur] : (const R4*)e->posm[cur];
+    const double W = e->cfg.bound_width;
+    const double lox = e->cfg.bound_center[0] - 0.5 * W, loy = e->cfg.bound_center[1] - 0.5 * W,
+                 loz = e->cfg.bound_center[2] - 0.5 * W;
+
+    if (e->timing) NBE_HIP(hipEventRecord(e->ev[0], e->stream));
+    NBE_HIP(hipMemsetAsync(w.counters, 0, 4 * sizeof(int), e->stream));
+    hipLaunchKernelGGL((keys_kernel<R4>), dim3(nb), dim3(256), 0, e->stream, force_pos, n, lox, loy, loz, W, w.keys[0],
+                       w.sidx[0], w.counters);
+    NBE_HIP(hipGetLastError());
+
+    // 63-bit keys plus the all-ones dead key: 8 passes of 8 bits, ending back in buffer 0.
+    const int nblocks = (int)cdiv(n, SORT_TILE);
+    int in = 0;
+    for (int pass = 0; pass < 8; pass++) {
+        const int shift = pass * 8;
+        hipLaunchKernelGGL(radix_hist_kernel, dim3(nblocks), dim3(256), 0, e->stream, w.keys[in], n, shift, nblocks,
+                           w.block_hist);
+        NBE_TRY((device_exclusive_scan<false>(e, w.block_hist, w.block_hist, (size_t)256 * nblocks)));
+        hipLaunchKernelGGL(radix_scatter_kernel, dim3(nblocks), dim3(256), 0, e->stream, w.keys[in], w.sidx[in],
+                           w.keys[in ^ 1], w.sidx[in ^ 1], w.block_hist, n, shift, nblocks);
+        NBE_HIP(hipGetLastError());
+        in ^= 1;
+    }
+    hipLaunchKernelGGL((permute_kernel<S4>), dim3(nb), dim3(256), 0, e->stream, w.sidx[0], n, (const S4*)e->posm[cur],
+                       (const S4*)e->vel[cur], e->orig[e->orig_cur], mixed ? e->mirror[cur] : (const float4*)nullptr,
+                       (S4*)e->posm[nxt], (S4*)e->vel[nxt], e->orig[e->orig_cur ^ 1], mixed ? e->mirror[nxt] : (float4*)nullptr);
+    NBE_HIP(hipGetLastError());
+    e->cur = nxt;
+    e->orig_cur ^= 1;
+    e->have_counts = true;
+    if (e->timing) NBE_HIP(hipEventRecord(e->ev[1], e->stream));
+
+    const R4* sorted_pos = mixed ? (const R4*)e->mirror[nxt] : (const R4*)e->posm[nxt];
+    hipLaunchKernelGGL(radix_tree_kernel, dim3(nb), dim3(256), 0, e->stream, w.keys[0], w.counters, w.bt_first, w.bt_last,
+                       w.bt_parent, w.bt_level);
+    NBE_HIP(hipMemsetAsync(w.lvlmask, 0, ((size_t)n + 1) * 4, e->stream));
+    hipLaunchKernelGGL(mark_cells_kernel, dim3(nb), dim3(256), 0, e->stream, w.counters, w.bt_first, w.bt_parent, w.bt_level,
+                       w.lvlmask);
+    NBE_HIP(hipGetLastError());
+    NBE_TRY((device_exclusive_scan<true>(e, w.lvlmask, w.cellcnt, (size_t)n + 1)));
+    hipLaunchKernelGGL((emit_nodes_kernel<R4, NodeT>), dim3(cdiv(2 * (size_t)n, 256)), dim3(256), 0, e->stream, n, w.counters,
+                       sorted_pos, w.bt_first, w.bt_last, w.bt_parent, w.bt_level, w.lvlmask, w.cellcnt, W, (NodeT*)w.nodes,
+                       w.node_level, w.node_sum);
+    NBE_HIP(hipGetLastError());
+    for (int level = 21; level >= 0; level--) {
+        hipLaunchKernelGGL((cell_mass_kernel<NodeT>), dim3(cdiv(2 * (size_t)n, 256)), dim3(256), 0, e->stream, w.counters,
+                           level, (NodeT*)w.nodes, w.node_level, w.node_sum);
+    }
+    NBE_HIP(hipGetLastError());
+    if (e->timing) NBE_HIP(hipEventRecord(e->ev[2], e->stream));
+    return NBE_OK;
+}
+
+// Sorts the current state by Morton key into the other buffer (which becomes current) and builds the tree
+// over it.  Everything is queued on the engine's stream; nothing is read back.
+int tree_sort_and_build(nbe_engine* e)
+{
+    NBE_TRY(tree_workspace_reserve(e));
+    if (e->n == 0) return NBE_OK;
+    if (e->n > 0x3fffffffull) { nbe_set_error("tree mode supports at most 2^30-1 bodies"); return NBE_E_UNSUPPORTED; }
+    switch (e->cfg.precision) {
+    case NBE_PREC_F32: return sort_and_build_t<float4, float4, NodeF>(e);
+    case NBE_PREC_MIXED: return sort_and_build_t<float4, double4, NodeF>(e);
+    case NBE_PREC_F64: return sort_and_build_t<double4, double4, NodeD>(e);
+    }
+    nbe_set_error("unknown precision %d", e->cfg.precision);
+    return NBE_E_INVALID;
+}

@@ -1,0 +1,144 @@
+// Wavefront-coherent Barnes-Hut traversal with the kick-drift integrator fused into the epilogue.
+//
+// Replaces (*node).gravity (tree.go:202-240) and its fan-out over four goroutines (main.go:134-149).
+// One lane owns one body; the 64 bodies of a wave are consecutive in Morton order, so they are close in
+// space and want nearly the same nodes.  The wave walks the pre-order node array with ONE shared cursor:
+//   * every lane applies the reference's own test to the node under the cursor: a branching cell is
+//     opened iff edge / |com - p| > theta (tree.go:216-217; evaluated as edge^2 > theta^2 * r^2 in fp32);
+//   * a lane that does not open it takes its force (tree.go:232-238) and remembers `skip`, the index after
+//     the node's subtree; while the cursor is below that index the lane sits out (it has already accounted
+//     for everything in there), exactly as its own recursion would have returned;
+//   * the cursor descends (index+1) if any lane opened the node, else jumps to `skip`.
+// So each body receives precisely the interactions its private depth-first walk would give it, in the
+// same order (children 0..7, tree.go:221-225), while node records are fetched once per wave through a
+// wave-uniform address.  Differences from the reference: the body's own leaf and bodies at distance 0
+// contribute nothing (the reference skips only the body itself and yields NaN for a coincident pair);
+// all bodies are walked (main.go:136-147 leaves out the last N mod 4).
+#include "engine_internal.h"
+#include "kernels_common.h"
+
+__device__ __forceinline__ bool node_opens(const NodeF& nd, float r2, float theta2, float) { return nd.w2 > theta2 * r2; }
+__device__ __forceinline__ bool node_opens(const NodeD& nd, double r2, double, double theta) { return nd.w / sqrt(r2) > theta; }
+
+template <typename R, typename A, typename NodeT, int OUT>
+__global__ __launch_bounds__(256) void walk_kernel(
+    const NodeT* __restrict__ nodes, const int* __restrict__ counters, const typename V4<R>::type* __restrict__ posm,
+    int t0, int t1, R theta, R floor2, A G, A dt, typename V4<A>::type* __restrict__ acc_out,
+    const typename V4<A>::type* __restrict__ pos_in, const typename V4<A>::type* __restrict__ vel_in,
+    typename V4<A>::type* __restrict__ pos_out, typename V4<A>::type* __restrict__ vel_out,
+    float4* __restrict__ mirror_out, unsigned long long* __restrict__ interactions)
+{
+    using R4 = typename V4<R>::type;
+    using A4 = typename V4<A>::type;
+    constexpr bool BLOCKED = !__is_same(R, A);
+    const int na = counters[0];
+    const int total = counters[1];
+    const int tend = t1 < na ? t1 : na;
+    const int i = t0 + blockIdx.x * 256 + threadIdx.x;
+    const bool valid = i < tend;
+    if (__ballot(valid) == 0) return;            // whole wave past the end
+
+    R px = 0, py = 0, pz = 0;
+    if (valid) { R4 p = posm[i]; px = p.x; py = p.y; pz = p.z; }
+    const R theta2 = theta * theta;
+    R fx = 0, fy = 0, fz = 0;
+    A ax = 0, ay = 0, az = 0;
+    int my_skip = valid ? 0 : 0x7fffffff;
+    unsigned count = 0;
+    int cur = 0;
+    int it = 0;
+    while (cur < total) {
+        const NodeT nd = nodes[cur];
+        const R dx = (R)nd.x - px, dy = (R)nd.y - py, dz = (R)nd.z - pz;
+        const R r2 = fma(dx, dx, fma(dy, dy, dz * dz));
+        const bool active = cur >= my_skip;
+        const bool open = active && node_opens(nd, r2, theta2, theta);
+        const bool take = active && !open;
+        if (take) my_skip = nd.skip;
+        const bool use = take && r2 > (R)0;
+        const R rinv = rsq_dev(r2 + floor2);
+        const R w = use ? (rinv * rinv) * (rinv * (R)nd.m) : (R)0;
+        fx = fma(dx, w, fx);
+        fy = fma(dy, w, fy);
+        fz = fma(dz, w, fz);
+        count += (unsigned)__popcll(__ballot(use));
+        const bool any_open = __ballot(open) != 0;
+        cur = __builtin_amdgcn_readfirstlane(any_open ? cur + 1 : nd.skip);
+        if (BLOCKED && ((++it) & 63) == 0) {
+            ax += (A)fx; ay += (A)fy; az += (A)fz;
+            fx = 0; fy = 0; fz = 0;
+        }
+    }
+    ax += (A)fx; ay += (A)fy; az += (A)fz;
+
+    if ((threadIdx.x & 63) == 0 && interactions) atomicAdd(interactions, (unsigned long long)count);
+    if (!valid) return;
+    if (OUT == OUT_ACC) {
+        A4 o; o.x = G * ax; o.y = G * ay; o.z = G * az; o.w = 0;
+        acc_out[i] = o;
+    } else {
+        kick_drift<A>(i, G * ax, G * ay, G * az, dt, pos_in, vel_in, pos_out, vel_out, mirror_out);
+    }
+}
+
+// Bodies past n_alive (removed by the bound check) are carried along unchanged when the state moves to the
+// next buffer.
+template <typename S4>
+__global__ __launch_bounds__(256) void carry_dead_kernel(const int* __restrict__ counters, int t0, int t1,
+                                                         const S4* __restrict__ pos_in, const S4* __restrict__ vel_in,
+                                                         const float4* __restrict__ mirror_in, S4* __restrict__ pos_out,
+                                                         S4* __restrict__ vel_out, float4* __restrict__ mirror_out)
+{
+    const int na = counters[0];
+    const int i = t0 + blockIdx.x * 256 + threadIdx.x;
+    if (i >= t1 || i < na) return;
+    pos_out[i] = pos_in[i];
+    vel_out[i] = vel_in[i];
+    if (mirror_in) mirror_out[i] = mirror_in[i];
+}
+
+template <typename R, typename A, typename NodeT>
+static int launch_walk(nbe_engine* e, const void* src, uint64_t t0, uint64_t t1, bool fused, int src_buf, int dst_buf)
+{
+    using R4 = typename V4<R>::type;
+    using A4 = typename V4<A>::type;
+    const size_t nt = (size_t)(t1 - t0);
+    if (nt == 0) return NBE_OK;
+    const double eps = e->cfg.eps;
+    const double tiny = __is_same(R, float) ? 1e-12 : 1e-60;
+    const R floor2 = (R)(eps * eps > tiny ? eps * eps : tiny);
+    const A G = (A)e->cfg.G, dt = (A)e->cfg.dt;
+    const bool mixed = e->cfg.precision == NBE_PREC_MIXED;
+    const A4* pos_in = (const A4*)e->posm[src_buf];
+    const A4* vel_in = (const A4*)e->vel[src_buf];
+    A4* pos_out = (A4*)e->posm[dst_buf];
+    A4* vel_out = (A4*)e->vel[dst_buf];
+    float4* mirror_out = mixed ? e->mirror[dst_buf] : nullptr;
+    NBE_HIP(hipMemsetAsync(e->tw.d_interactions, 0, sizeof(unsigned long long), e->stream));
+    dim3 grid(cdiv(nt, 256));
+    if (fused) {
+        hipLaunchKernelGGL((walk_kernel<R, A, NodeT, OUT_FUSED>), grid, dim3(256), 0, e->stream, (const NodeT*)e->tw.nodes,
+                           e->tw.counters, (const R4*)src, (int)t0, (int)t1, (R)e->cfg.theta, floor2, G, dt, (A4*)e->acc,
+                           pos_in, vel_in, pos_out, vel_out, mirror_out, e->tw.d_interactions);
+        hipLaunchKernelGGL((carry_dead_kernel<A4>), grid, dim3(256), 0, e->stream, e->tw.counters, (int)t0, (int)t1, pos_in,
+                           vel_in, mixed ? e->mirror[src_buf] : (const float4*)nullptr, pos_out, vel_out, mirror_out);
+    } else {
+        hipLaunchKernelGGL((walk_kernel<R, A, NodeT, OUT_ACC>), grid, dim3(256), 0, e->stream, (const NodeT*)e->tw.nodes,
+                           e->tw.counters, (const R4*)src, (int)t0, (int)t1, (R)e->cfg.theta, floor2, G, dt, (A4*)e->acc,
+                           pos_in, vel_in, pos_out, vel_out, mirror_out, e->tw.d_interactions);
+    }
+    NBE_HIP(hipGetLastError());
+    return NBE_OK;
+}
+
+// Forces on sorted targets [t0, t1) of buffer `src_buf` from the tree built over that buffer.
+int tree_forces(nbe_engine* e, int src_buf, uint64_t t0, uint64_t t1, bool fused, int dst_buf)
+{
+    switch (e->cfg.precision) {
+    case NBE_PREC_F32: return launch_walk<float, float, NodeF>(e, e->posm[src_buf], t0, t1, fused, src_buf, dst_buf);
+    case NBE_PREC_MIXED: return launch_walk<float, double, NodeF>(e, e->mirror[src_buf], t0, t1, fused, src_buf, dst_buf);
+    case NBE_PREC_F64: return launch_walk<double, double, NodeD>(e, e->posm[src_buf], t0, t1, fused, src_buf, dst_buf);
+    }
+    nbe_set_error("unknown precision %d", e->cfg.precision);
+    return NBE_E_INVALID;
+}

@@ -1,0 +1,228 @@
+"""ctypes binding of libnbody_engine.so (C ABI in include/nbody_engine.h).
+
+There is no CPU fallback: loading fails loudly when the HIP library has not been built, and Engine()
+fails when no GPU is present.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+MODE_DIRECT, MODE_TREE = 0, 1
+PREC_F32, PREC_MIXED, PREC_F64 = 0, 1, 2
+_MODES = {"direct": MODE_DIRECT, "tree": MODE_TREE}
+_PRECS = {"f32": PREC_F32, "mixed": PREC_MIXED, "f64": PREC_F64}
+
+# Every symbol include/nbody_engine.h declares.
+EXPORTS = ("nbe_default_config", "nbe_create", "nbe_destroy", "nbe_last_error", "nbe_upload", "nbe_download",
+           "nbe_accel", "nbe_step", "nbe_step_timed", "nbe_sync", "nbe_stats", "nbe_energy", "nbe_set_shard",
+           "nbe_shard_prepare", "nbe_shard_advance", "nbe_shard_commit", "nbe_device_state", "nbe_set_stream",
+           "nbe_time_force_kernel")
+
+
+class Config(C.Structure):
+    _fields_ = [("mode", C.c_int), ("precision", C.c_int), ("G", C.c_double), ("theta", C.c_double),
+                ("dt", C.c_double), ("eps", C.c_double), ("bound_center", C.c_double * 3),
+                ("bound_width", C.c_double), ("device", C.c_int), ("reserved", C.c_int)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("n", C.c_uint64), ("n_alive", C.c_uint64), ("steps", C.c_uint64), ("interactions", C.c_uint64),
+                ("tree_nodes", C.c_uint64), ("tree_cells", C.c_uint64), ("ms_sort", C.c_float),
+                ("ms_build", C.c_float), ("ms_force", C.c_float), ("ms_total", C.c_float)]
+
+
+class DeviceState(C.Structure):
+    _fields_ = [("pos_mass", C.c_void_p), ("vel", C.c_void_p), ("pos_mass_next", C.c_void_p),
+                ("vel_next", C.c_void_p), ("n", C.c_uint64), ("elem_bytes", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class EngineError(RuntimeError):
+    """A C-ABI call returned a non-zero code (the reference panics on every error, main.go:213-238)."""
+
+
+def library_path():
+    return os.path.join(_HERE, "libnbody_engine.so")
+
+
+_lib = None
+
+
+def load_library():
+    """dlopen the engine and declare every entry point's signature."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise EngineError(f"{path} is missing: build it with `make -C nbody_amd/csrc` "
+                          "(or __graft_entry__.build()); there is no CPU fallback")
+    lib = C.CDLL(path)
+    dp, u64p, u8p = C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint8)
+    vp = C.c_void_p
+    lib.nbe_default_config.argtypes = [C.POINTER(Config)]
+    lib.nbe_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
+    lib.nbe_destroy.argtypes = [vp]
+    lib.nbe_destroy.restype = None
+    lib.nbe_last_error.argtypes = []
+    lib.nbe_last_error.restype = C.c_char_p
+    lib.nbe_upload.argtypes = [vp, C.c_size_t, dp, dp, dp, u64p]
+    lib.nbe_download.argtypes = [vp, dp, dp, dp, u64p, C.POINTER(C.c_size_t)]
+    lib.nbe_accel.argtypes = [vp, dp, u8p]
+    lib.nbe_step.argtypes = [vp, C.c_int]
+    lib.nbe_step_timed.argtypes = [vp, C.POINTER(Stats)]
+    lib.nbe_sync.argtypes = [vp]
+    lib.nbe_stats.argtypes = [vp, C.POINTER(Stats)]
+    lib.nbe_energy.argtypes = [vp, dp, dp, dp]
+    lib.nbe_set_shard.argtypes = [vp, C.c_uint64, C.c_uint64]
+    lib.nbe_shard_prepare.argtypes = [vp]
+    lib.nbe_shard_advance.argtypes = [vp]
+    lib.nbe_shard_commit.argtypes = [vp]
+    lib.nbe_device_state.argtypes = [vp, C.POINTER(DeviceState)]
+    lib.nbe_set_stream.argtypes = [vp, vp]
+    lib.nbe_time_force_kernel.argtypes = [vp, C.c_int, C.POINTER(C.c_float)]
+    for name in EXPORTS:
+        if name not in ("nbe_destroy", "nbe_last_error"):
+            getattr(lib, name).restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+class Engine:
+    """One engine per GPU.  Mirrors the reference's step seam (main.go:104-178): upload the live bodies,
+    step(), download the copy a frame would take (main.go:90-101)."""
+
+    def __init__(self, mode="direct", precision="f32", theta=None, dt=None, eps=None, G=None,
+                 bound_center=None, bound_width=None, device=0):
+        self._lib = load_library()
+        cfg = Config()
+        self._check(self._lib.nbe_default_config(C.byref(cfg)))
+        cfg.mode = _MODES[mode] if isinstance(mode, str) else int(mode)
+        cfg.precision = _PRECS[precision] if isinstance(precision, str) else int(precision)
+        if theta is not None:
+            cfg.theta = float(theta)
+        if dt is not None:
+            cfg.dt = float(dt)
+        if eps is not None:
+            cfg.eps = float(eps)
+        if G is not None:
+            cfg.G = float(G)
+        if bound_center is not None:
+            cfg.bound_center[:] = [float(c) for c in bound_center]
+        if bound_width is not None:
+            cfg.bound_width = float(bound_width)
+        cfg.device = int(device)
+        self.cfg = cfg
+        self._h = C.c_void_p()
+        self._check(self._lib.nbe_create(C.byref(cfg), C.byref(self._h)))
+        self.n = 0
+
+    def _check(self, rc):
+        if rc != 0:
+            raise EngineError(f"nbody_engine error {rc}: {self._lib.nbe_last_error().decode()}")
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.nbe_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # ---- state ----
+    def upload(self, pos, vel, mass, ids=None):
+        pos = np.ascontiguousarray(pos, dtype=np.float64).reshape(-1, 3)
+        vel = np.ascontiguousarray(vel, dtype=np.float64).reshape(-1, 3)
+        mass = np.ascontiguousarray(mass, dtype=np.float64).reshape(-1)
+        n = mass.shape[0]
+        if pos.shape[0] != n or vel.shape[0] != n:
+            raise ValueError("pos, vel and mass disagree on the number of bodies")
+        idp = None
+        if ids is not None:
+            ids = np.ascontiguousarray(ids, dtype=np.uint64)
+            if ids.shape[0] != n:
+                raise ValueError("ids has the wrong length")
+            idp = ids.ctypes.data_as(C.POINTER(C.c_uint64))
+        self._check(self._lib.nbe_upload(self._h, n, _dp(pos), _dp(vel), _dp(mass), idp))
+        self.n = n
+
+    def download(self):
+        """Returns (pos[k,3], vel[k,3], mass[k], ids[k]) of the k live bodies in upload order."""
+        n = self.n
+        pos = np.zeros((n, 3)); vel = np.zeros((n, 3)); mass = np.zeros(n); ids = np.zeros(n, dtype=np.uint64)
+        k = C.c_size_t(0)
+        self._check(self._lib.nbe_download(self._h, _dp(pos), _dp(vel), _dp(mass),
+                                           ids.ctypes.data_as(C.POINTER(C.c_uint64)), C.byref(k)))
+        k = k.value
+        return pos[:k], vel[:k], mass[:k], ids[:k]
+
+    # ---- force / step ----
+    def accel(self):
+        """Accelerations f/m of all uploaded bodies (upload order) and their alive flags."""
+        acc = np.zeros((self.n, 3))
+        alive = np.ones(self.n, dtype=np.uint8)
+        self._check(self._lib.nbe_accel(self._h, _dp(acc), alive.ctypes.data_as(C.POINTER(C.c_uint8))))
+        return acc, alive
+
+    def step(self, nsteps=1):
+        self._check(self._lib.nbe_step(self._h, int(nsteps)))
+
+    def step_timed(self):
+        st = Stats()
+        self._check(self._lib.nbe_step_timed(self._h, C.byref(st)))
+        return st
+
+    def sync(self):
+        self._check(self._lib.nbe_sync(self._h))
+
+    def stats(self):
+        st = Stats()
+        self._check(self._lib.nbe_stats(self._h, C.byref(st)))
+        return st
+
+    def energy(self):
+        ke, pe = C.c_double(), C.c_double()
+        mom = np.zeros(3)
+        self._check(self._lib.nbe_energy(self._h, C.byref(ke), C.byref(pe), _dp(mom)))
+        return ke.value, pe.value, mom
+
+    def time_force_kernel(self, reps=5):
+        ms = C.c_float()
+        self._check(self._lib.nbe_time_force_kernel(self._h, int(reps), C.byref(ms)))
+        return ms.value
+
+    # ---- sharded stepping ----
+    def set_shard(self, first, count):
+        self._check(self._lib.nbe_set_shard(self._h, int(first), int(count)))
+
+    def shard_prepare(self):
+        self._check(self._lib.nbe_shard_prepare(self._h))
+
+    def shard_advance(self):
+        self._check(self._lib.nbe_shard_advance(self._h))
+
+    def shard_commit(self):
+        self._check(self._lib.nbe_shard_commit(self._h))
+
+    def device_state(self):
+        ds = DeviceState()
+        self._check(self._lib.nbe_device_state(self._h, C.byref(ds)))
+        return ds
+
+    def set_stream(self, hip_stream):
+        self._check(self._lib.nbe_set_stream(self._h, C.c_void_p(hip_stream)))
