@@ -127,8 +127,18 @@ int nbe_shard_advance(nbe_engine *e);
 int nbe_shard_commit(nbe_engine *e);
 int nbe_device_state(nbe_engine *e, nbe_device_state_t *out);
 
-/* Run the engine's work on a caller-owned hipStream_t (NULL restores the engine's own stream). */
+/* Run the engine's work on a caller-owned hipStream_t instead of the engine's own non-blocking stream, so
+ * that it is ordered with the caller's other work (copies, collectives).  NULL selects HIP's default (null)
+ * stream.  The previous stream is drained first. */
 int nbe_set_stream(nbe_engine *e, void *hip_stream);
+
+/* ---- tree inspection (tests) ----
+ * Builds the tree of the current state if needed and copies its nodes to the host in depth-first pre-order
+ * (children in octant order 0..7, the order of tree.go:221-225): 6 doubles per node = centre of mass x,y,z,
+ * mass, cell edge (0 for a one-body leaf; tree.go:60-62 for a cell) and the pre-order index of the first
+ * node after its subtree.  One-child chains of the reference's pointer tree are not materialised.
+ * *count receives the number of nodes; at most `cap` are written. */
+int nbe_tree_nodes(nbe_engine *e, double *out, size_t cap, size_t *count);
 
 /* ---- dominant-kernel timing for benchmarks ----
  * Runs `reps` back-to-back launches of the force kernel of the current mode on the current state without

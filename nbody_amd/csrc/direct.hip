@@ -14,7 +14,7 @@
 #include "kernels_common.h"
 
 // R: type of the pair arithmetic; A: type of the running sums and of the state (A == R, or R = float with
-// A = double, in which case each 256-source tile is summed in fp32 and the tile sums in fp64).
+// A = double).  Each 256-source tile is summed in R and the tile sums are accumulated in A.
 template <typename R, typename A, int ITILE, int OUT>
 __global__ __launch_bounds__(256) void direct_kernel(
     const typename V4<R>::type* __restrict__ src, int n_src, int t0, int t1, int jchunk, R floor2, A G, A dt,
@@ -25,7 +25,6 @@ __global__ __launch_bounds__(256) void direct_kernel(
 {
     using R4 = typename V4<R>::type;
     using A4 = typename V4<A>::type;
-    constexpr bool BLOCKED = !__is_same(R, A);
     __shared__ R4 sh[256];
     const int tid = threadIdx.x;
     const int ibase = t0 + blockIdx.x * (256 * ITILE);
@@ -54,12 +53,11 @@ __global__ __launch_bounds__(256) void direct_kernel(
         nxt = pad;
         if (jt + 256 + tid < je) nxt = src[jt + 256 + tid];
 
+        // Sums are blocked: one partial per 256-source tile, added to the running total afterwards.  This
+        // keeps fp32 rounding growth at ~sqrt(256) + sqrt(N/256) ulps instead of ~sqrt(N).
         R fx[ITILE], fy[ITILE], fz[ITILE];
 #pragma unroll
-        for (int k = 0; k < ITILE; k++) {
-            if (BLOCKED) { fx[k] = 0; fy[k] = 0; fz[k] = 0; }
-            else { fx[k] = (R)ax[k]; fy[k] = (R)ay[k]; fz[k] = (R)az[k]; }
-        }
+        for (int k = 0; k < ITILE; k++) { fx[k] = 0; fy[k] = 0; fz[k] = 0; }
 #pragma unroll 8
         for (int jj = 0; jj < 256; jj++) {
             const R4 s = sh[jj];
@@ -75,10 +73,7 @@ __global__ __launch_bounds__(256) void direct_kernel(
             }
         }
 #pragma unroll
-        for (int k = 0; k < ITILE; k++) {
-            if (BLOCKED) { ax[k] += (A)fx[k]; ay[k] += (A)fy[k]; az[k] += (A)fz[k]; }
-            else { ax[k] = (A)fx[k]; ay[k] = (A)fy[k]; az[k] = (A)fz[k]; }
-        }
+        for (int k = 0; k < ITILE; k++) { ax[k] += (A)fx[k]; ay[k] += (A)fy[k]; az[k] += (A)fz[k]; }
     }
 
 #pragma unroll

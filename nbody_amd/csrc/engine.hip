@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <cstdarg>
+#include <cmath>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -109,7 +110,7 @@ extern "C" int nbe_set_stream(nbe_engine* e, void* hip_stream)
     if (!e) { nbe_set_error("engine is NULL"); return NBE_E_INVALID; }
     NBE_TRY(use_device(e));
     NBE_HIP(hipStreamSynchronize(e->stream));
-    e->stream = hip_stream ? (hipStream_t)hip_stream : e->own_stream;
+    e->stream = (hipStream_t)hip_stream;
     return NBE_OK;
 }
 
@@ -263,10 +264,30 @@ extern "C" int nbe_shard_advance(nbe_engine* e)
     return NBE_OK;
 }
 
+// MIXED precision keeps an fp32 copy of the positions for the force kernels.  An advance refreshes it only
+// for the engine's own shard; rows that arrive from other engines through the caller's all-gather are
+// converted here.
+__global__ __launch_bounds__(256) void refresh_mirror_kernel(const double4* __restrict__ posm, float4* __restrict__ mirror,
+                                                             int n, int skip_first, int skip_end)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n || (i >= skip_first && i < skip_end)) return;
+    const double4 p = posm[i];
+    mirror[i] = make_float4((float)p.x, (float)p.y, (float)p.z, (float)p.w);
+}
+
 extern "C" int nbe_shard_commit(nbe_engine* e)
 {
     if (!e) { nbe_set_error("engine is NULL"); return NBE_E_INVALID; }
     if (!e->advance_pending) { nbe_set_error("nbe_shard_commit without nbe_shard_advance"); return NBE_E_INVALID; }
+    NBE_TRY(use_device(e));
+    if (e->cfg.precision == NBE_PREC_MIXED && e->shard_set && e->shard_count < e->n) {
+        const int nxt = e->cur ^ 1;
+        hipLaunchKernelGGL(refresh_mirror_kernel, dim3(cdiv(e->n, 256)), dim3(256), 0, e->stream,
+                           (const double4*)e->posm[nxt], e->mirror[nxt], (int)e->n, (int)e->shard_first,
+                           (int)(e->shard_first + e->shard_count));
+        NBE_HIP(hipGetLastError());
+    }
     e->cur ^= 1;
     e->advance_pending = false;
     e->prepared = false;
@@ -441,5 +462,40 @@ extern "C" int nbe_time_force_kernel(nbe_engine* e, int reps, float* ms_per_laun
     NBE_HIP(hipEventElapsedTime(&ms, e->ev[0], e->ev[3]));
     *ms_per_launch = ms / (float)reps;
     NBE_TRY(fetch_interactions(e));
+    return NBE_OK;
+}
+
+extern "C" int nbe_tree_nodes(nbe_engine* e, double* out, size_t cap, size_t* count)
+{
+    if (!e || !count) { nbe_set_error("NULL argument"); return NBE_E_INVALID; }
+    NBE_TRY(use_device(e));
+    *count = 0;
+    if (e->cfg.mode != NBE_MODE_TREE) { nbe_set_error("nbe_tree_nodes needs tree mode"); return NBE_E_INVALID; }
+    if (e->advance_pending) { nbe_set_error("nbe_tree_nodes inside a sharded step"); return NBE_E_INVALID; }
+    if (e->n == 0) return NBE_OK;
+    if (!e->prepared) { NBE_TRY(tree_sort_and_build(e)); e->prepared = true; }
+    size_t na;
+    NBE_TRY(read_counts(e, &na));
+    const size_t total = (size_t)e->stats.tree_nodes;
+    *count = total;
+    const size_t m = total < cap ? total : cap;
+    if (m == 0 || !out) return NBE_OK;
+    if (e->force64) {
+        std::vector<NodeD> h(m);
+        NBE_HIP(hipMemcpyAsync(h.data(), e->tw.nodes, m * sizeof(NodeD), hipMemcpyDeviceToHost, e->stream));
+        NBE_HIP(hipStreamSynchronize(e->stream));
+        for (size_t i = 0; i < m; i++) {
+            out[6 * i] = h[i].x; out[6 * i + 1] = h[i].y; out[6 * i + 2] = h[i].z; out[6 * i + 3] = h[i].m;
+            out[6 * i + 4] = h[i].w; out[6 * i + 5] = (double)h[i].skip;
+        }
+    } else {
+        std::vector<NodeF> h(m);
+        NBE_HIP(hipMemcpyAsync(h.data(), e->tw.nodes, m * sizeof(NodeF), hipMemcpyDeviceToHost, e->stream));
+        NBE_HIP(hipStreamSynchronize(e->stream));
+        for (size_t i = 0; i < m; i++) {
+            out[6 * i] = h[i].x; out[6 * i + 1] = h[i].y; out[6 * i + 2] = h[i].z; out[6 * i + 3] = h[i].m;
+            out[6 * i + 4] = sqrt((double)h[i].w2); out[6 * i + 5] = (double)h[i].skip;
+        }
+    }
     return NBE_OK;
 }

@@ -19,7 +19,7 @@ _PRECS = {"f32": PREC_F32, "mixed": PREC_MIXED, "f64": PREC_F64}
 EXPORTS = ("nbe_default_config", "nbe_create", "nbe_destroy", "nbe_last_error", "nbe_upload", "nbe_download",
            "nbe_accel", "nbe_step", "nbe_step_timed", "nbe_sync", "nbe_stats", "nbe_energy", "nbe_set_shard",
            "nbe_shard_prepare", "nbe_shard_advance", "nbe_shard_commit", "nbe_device_state", "nbe_set_stream",
-           "nbe_time_force_kernel")
+           "nbe_time_force_kernel", "nbe_tree_nodes")
 
 
 class Config(C.Structure):
@@ -83,6 +83,7 @@ def load_library():
     lib.nbe_device_state.argtypes = [vp, C.POINTER(DeviceState)]
     lib.nbe_set_stream.argtypes = [vp, vp]
     lib.nbe_time_force_kernel.argtypes = [vp, C.c_int, C.POINTER(C.c_float)]
+    lib.nbe_tree_nodes.argtypes = [vp, dp, C.c_size_t, C.POINTER(C.c_size_t)]
     for name in EXPORTS:
         if name not in ("nbe_destroy", "nbe_last_error"):
             getattr(lib, name).restype = C.c_int
@@ -205,6 +206,15 @@ class Engine:
         ms = C.c_float()
         self._check(self._lib.nbe_time_force_kernel(self._h, int(reps), C.byref(ms)))
         return ms.value
+
+    def tree_nodes(self):
+        """Pre-order node table [nodes, 6]: com x,y,z, mass, cell edge (0 = leaf), skip index."""
+        cnt = C.c_size_t(0)
+        self._check(self._lib.nbe_tree_nodes(self._h, None, 0, C.byref(cnt)))
+        out = np.zeros((cnt.value, 6))
+        if cnt.value:
+            self._check(self._lib.nbe_tree_nodes(self._h, _dp(out), cnt.value, C.byref(cnt)))
+        return out
 
     # ---- sharded stepping ----
     def set_shard(self, first, count):

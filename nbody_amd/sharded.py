@@ -1,0 +1,120 @@
+"""Multi-GPU stepping: one process and one engine per GPU, targets sharded, sources replicated.
+
+The reference's only data-parallel strategy gives each of four goroutines a contiguous quarter of the
+bodies against a shared read-only tree (main.go:134-149).  Here a rank is such a worker: it holds all n
+bodies as sources, advances only its contiguous range of targets, and the ranks exchange the advanced
+ranges with one all-gather per state array per step (torch.distributed: backend "nccl" is RCCL over xGMI;
+"gloo" is used for CPU rehearsals and stages device buffers through the host).  In tree mode every rank
+sorts and builds the same tree over the same replicated state, so the sorted order, and with it the meaning
+of a target range, is identical everywhere.
+"""
+import numpy as np
+
+try:
+    import torch
+    import torch.distributed as dist
+except Exception:  # pragma: no cover - torch is part of the image
+    torch = None
+    dist = None
+
+
+def shard_range(n, rank, world):
+    """Contiguous range of ceil(n/world) targets per rank (the last ranks may get fewer or none)."""
+    per = (n + world - 1) // world
+    first = min(rank * per, n)
+    return first, min(per, n - first), per
+
+
+class _DevicePtr:
+    """Exposes a raw device pointer through __cuda_array_interface__ so torch can wrap it without copying."""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (int(ptr), False), "version": 3}
+
+
+def _wrap(ptr, n, elem_bytes, device):
+    t = torch.as_tensor(_DevicePtr(ptr, n * elem_bytes), device=device)
+    dtype = torch.float32 if elem_bytes == 16 else torch.float64
+    return t.view(dtype).view(n, 4)
+
+
+class EngineShard:
+    """Adapter between an nbody_amd.Engine and the stepper: exposes the engine's next-state buffers as
+    torch tensors that alias device memory."""
+
+    def __init__(self, engine, device_index=0, use_current_stream=True):
+        self.engine = engine
+        self.n = engine.n
+        self.device = torch.device("cuda", device_index)
+        if use_current_stream:
+            engine.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+        self._views = {}
+
+    def set_shard(self, first, count):
+        self.engine.set_shard(first, count)
+
+    def prepare(self):
+        self.engine.shard_prepare()
+
+    def advance(self):
+        self.engine.shard_advance()
+
+    def commit(self):
+        self.engine.shard_commit()
+
+    def next_state(self):
+        ds = self.engine.device_state()
+        out = []
+        for ptr in (ds.pos_mass_next, ds.vel_next):
+            if ptr not in self._views:
+                self._views[ptr] = _wrap(ptr, self.n, ds.elem_bytes, self.device)
+            out.append(self._views[ptr])
+        return out
+
+
+class ShardedStepper:
+    """Drives one rank's shard.  `shard` is an EngineShard (or anything with the same methods)."""
+
+    def __init__(self, shard, rank=None, world=None, group=None):
+        self.shard = shard
+        self.group = group
+        self.rank = dist.get_rank(group) if rank is None else rank
+        self.world = dist.get_world_size(group) if world is None else world
+        self.n = shard.n
+        self.first, self.count, self.per = shard_range(self.n, self.rank, self.world)
+        shard.set_shard(self.first, self.count)
+        self.even = self.per * self.world == self.n
+        self.backend = dist.get_backend(group) if self.world > 1 else None
+        self._pad = {}
+
+    def _gather(self, full):
+        """All-gather the ranks' row ranges of `full` (n x 4) in place."""
+        if self.world == 1:
+            return
+        host_stage = self.backend == "gloo" and full.is_cuda
+        work = full.cpu() if host_stage else full
+        if self.even:
+            mine = work[self.first:self.first + self.count]
+            dist.all_gather_into_tensor(work, mine, group=self.group)
+        else:
+            key = (work.dtype, work.device)
+            if key not in self._pad:
+                self._pad[key] = (torch.zeros(self.per * self.world, 4, dtype=work.dtype, device=work.device),
+                                  torch.zeros(self.per, 4, dtype=work.dtype, device=work.device))
+            padded, mine = self._pad[key]
+            mine[:self.count] = work[self.first:self.first + self.count]
+            dist.all_gather_into_tensor(padded, mine, group=self.group)
+            for r in range(self.world):
+                f, c, _ = shard_range(self.n, r, self.world)
+                if c:
+                    work[f:f + c] = padded[r * self.per:r * self.per + c]
+        if host_stage:
+            full.copy_(work)
+
+    def step(self, nsteps=1):
+        for _ in range(nsteps):
+            self.shard.prepare()
+            self.shard.advance()
+            for t in self.shard.next_state():
+                self._gather(t)
+            self.shard.commit()

@@ -1,0 +1,85 @@
+"""Worker of the world_size-2 rehearsals (started by tests/test_sharded_gloo.py and the GPU variant).
+
+argv: out_prefix mode n nsteps engine_kind
+engine_kind "oracle": a CPU stand-in shard whose force pass is the CPU oracle, so that the sharding and
+gather logic of nbody_amd.sharded can be exercised without a GPU.  "gpu": real engines (all ranks share
+cuda:0; gloo stages the gathers through the host).
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from nbody_amd import physics  # noqa: E402
+from nbody_amd.sharded import ShardedStepper  # noqa: E402
+
+
+class OracleShard:
+    """Same methods as nbody_amd.sharded.EngineShard, state in CPU tensors, forces from the CPU oracle."""
+
+    def __init__(self, bodies, mode, theta, dt):
+        from oracle import oracle as O
+        self.O = O
+        self.n = len(bodies)
+        self.mode, self.theta, self.dt = mode, theta, dt
+        self.cur = [torch.from_numpy(np.concatenate([bodies.pos, bodies.mass[:, None]], 1).copy()),
+                    torch.from_numpy(np.concatenate([bodies.vel, np.zeros((self.n, 1))], 1).copy())]
+        self.nxt = [torch.zeros_like(self.cur[0]), torch.zeros_like(self.cur[1])]
+        self.first, self.count = 0, self.n
+
+    def set_shard(self, first, count):
+        self.first, self.count = first, count
+
+    def prepare(self):
+        pass
+
+    def advance(self):
+        pos = self.cur[0][:, :3].numpy(); mass = self.cur[0][:, 3].numpy(); vel = self.cur[1][:, :3].numpy()
+        if self.mode == "tree":
+            f, _, _ = self.O.forces(mass, pos, mode="tree", com_mode="true", theta=self.theta, drop_tail=False)
+        else:
+            f = self.O.direct_rows(mass, pos, nthreads=2)
+        s = slice(self.first, self.first + self.count)
+        v = vel[s] + f[s] / mass[s, None] * self.dt
+        p = pos[s] + v * self.dt
+        self.nxt[0][s, :3] = torch.from_numpy(p); self.nxt[0][s, 3] = self.cur[0][s, 3]
+        self.nxt[1][s, :3] = torch.from_numpy(v)
+
+    def next_state(self):
+        return self.nxt
+
+    def commit(self):
+        self.cur, self.nxt = self.nxt, self.cur
+
+
+def main():
+    out_prefix, mode, n, nsteps, kind = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    bodies = physics.makebodies(n - 2, seed=11)
+    if kind == "oracle":
+        shard = OracleShard(bodies, mode, 0.5, 3600.0)
+        stepper = ShardedStepper(shard)
+        stepper.step(nsteps)
+        pos = shard.cur[0][:, :3].numpy(); vel = shard.cur[1][:, :3].numpy()
+    else:
+        from nbody_amd import Engine
+        from nbody_amd.sharded import EngineShard
+        prec = sys.argv[6]
+        eng = Engine(mode=mode, precision=prec, theta=0.5)
+        eng.upload(bodies.pos, bodies.vel, bodies.mass)
+        stepper = ShardedStepper(EngineShard(eng))
+        stepper.step(nsteps)
+        pos, vel, _, _ = eng.download()
+    np.savez(f"{out_prefix}.rank{rank}.npz", pos=pos, vel=vel, first=stepper.first, count=stepper.count)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

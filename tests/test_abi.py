@@ -1,0 +1,69 @@
+"""The C-ABI library: it loads, exports every symbol the header declares, and validates arguments.
+No compute calls here (no GPU needed); on a machine without a GPU engine creation must fail loudly."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from nbody_amd import engine as E
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "nbody_engine.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(nbe_[a-z_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = E.load_library()
+    syms = header_symbols()
+    assert len(syms) >= 19
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in nbody_engine.h but not exported"
+    assert sorted(E.EXPORTS) == syms
+
+
+def test_struct_layouts_match_header_sizes():
+    assert C.sizeof(E.Config) == 2 * 4 + 4 * 8 + 3 * 8 + 8 + 2 * 4
+    assert C.sizeof(E.Stats) == 6 * 8 + 4 * 4
+    assert C.sizeof(E.DeviceState) == 4 * 8 + 8 + 4 + 4
+
+
+def test_default_config_holds_reference_constants():
+    lib = E.load_library()
+    cfg = E.Config()
+    assert lib.nbe_default_config(C.byref(cfg)) == 0
+    assert cfg.G == 6.67408e-11 and cfg.theta == 1.0 and cfg.dt == 3600.0 and cfg.eps == 0.0
+    assert cfg.bound_width == 65536.0 and list(cfg.bound_center) == [0.0, 0.0, 0.0]
+    assert cfg.mode == E.MODE_DIRECT and cfg.precision == E.PREC_F32
+    assert lib.nbe_default_config(None) == -1
+    assert b"NULL" in lib.nbe_last_error()
+
+
+def test_create_rejects_bad_arguments():
+    lib = E.load_library()
+    cfg = E.Config()
+    lib.nbe_default_config(C.byref(cfg))
+    h = C.c_void_p()
+    cfg.mode = 7
+    assert lib.nbe_create(C.byref(cfg), C.byref(h)) == -1 and not h.value
+    cfg.mode = 1
+    cfg.precision = 9
+    assert lib.nbe_create(C.byref(cfg), C.byref(h)) == -1
+    cfg.precision = 0
+    cfg.bound_width = 0.0
+    assert lib.nbe_create(C.byref(cfg), C.byref(h)) == -1
+    assert lib.nbe_create(None, C.byref(h)) == -1
+    assert lib.nbe_step(None, 1) == -1 and lib.nbe_upload(None, 0, None, None, None, None) == -1
+
+
+def test_no_cpu_fallback_without_a_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(E.EngineError) as ei:
+        E.Engine()
+    assert "no HIP device" in str(ei.value) or "device" in str(ei.value)

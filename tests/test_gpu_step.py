@@ -1,0 +1,103 @@
+"""Whole-step behaviour on the GPU: energy and momentum drift, sharded stepping, timing/stat plumbing."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from nbody_amd import Engine, physics
+from oracle import oracle as O
+from tests.test_sharded_gloo import run_ranks
+
+pytestmark = pytest.mark.gpu
+
+
+def test_energy_matches_oracle(gpu):
+    b = physics.plummer(3000, seed=2)
+    for precision in ("f32", "f64"):
+        with Engine(mode="direct", precision=precision, eps=3.0) as e:
+            e.upload(b.pos, b.vel, b.mass)
+            ke, pe, mom = e.energy()
+        oke, ope, omom = O.energy(b.mass, b.pos, b.vel, eps=3.0)
+        tol = 1e-12 if precision == "f64" else 1e-5
+        assert abs(ke - oke) <= tol * oke and abs(pe - ope) <= tol * abs(ope)
+        assert np.abs(mom - omom).max() <= tol * (b.mass * np.linalg.norm(b.vel, axis=1)).sum()
+
+
+@pytest.mark.parametrize("mode,precision", [("direct", "f64"), ("direct", "mixed"), ("tree", "mixed"), ("tree", "f64")])
+def test_energy_and_momentum_drift_two_galaxies(gpu, mode, precision):
+    """Scaled-down BASELINE config 5 (two Plummer spheres on the reference cores' approach course): kick-drift
+    Euler with eps = 20 m and dt = 3600 s (dynamical time of each sphere ~ 2e5 s, so dt ~ t_dyn/55).
+    Bounds over 300 steps: |dE/E0| <= 2e-3; |dP| / sum m|v| <= 1e-10 for the direct sum (pairwise forces
+    cancel up to rounding) and <= 2e-3 for Barnes-Hut at theta = 0.5 (cell forces are not pairwise)."""
+    b = physics.galaxy_pair(4096, a=1.5e3, total_mass=1e9, seed=5)
+    with Engine(mode=mode, precision=precision, theta=0.5, eps=20.0) as e:
+        e.upload(b.pos, b.vel, b.mass)
+        ke0, pe0, p0 = e.energy()
+        e.step(300)
+        ke1, pe1, p1 = e.energy()
+        st = e.stats()
+    assert st.n_alive == len(b) and st.steps == 300
+    e0, e1 = ke0 + pe0, ke1 + pe1
+    assert abs((e1 - e0) / e0) <= 2e-3
+    pscale = (b.mass * np.linalg.norm(b.vel, axis=1)).sum()
+    assert np.linalg.norm(p1 - p0) / pscale <= (1e-10 if mode == "direct" and precision == "f64" else
+                                                 1e-7 if mode == "direct" else 2e-3)
+
+
+def test_step_timed_reports_phases(gpu):
+    b = physics.plummer(1 << 16, seed=1)
+    with Engine(mode="tree", precision="f32", theta=0.5) as e:
+        e.upload(b.pos, b.vel, b.mass)
+        e.step(1)
+        st = e.step_timed()
+        assert st.ms_sort > 0 and st.ms_build > 0 and st.ms_force > 0
+        assert abs(st.ms_total - (st.ms_sort + st.ms_build + st.ms_force)) < 0.05 * st.ms_total + 0.01
+        assert st.interactions > 0 and st.steps == 2
+        ms = e.time_force_kernel(3)
+        assert 0 < ms < 100
+    with Engine(mode="direct", precision="f32") as e:
+        e.upload(b.pos, b.vel, b.mass)
+        st = e.step_timed()
+        assert st.ms_force > 0 and st.interactions == (1 << 16) * ((1 << 16) - 1)
+
+
+def test_call_order_errors(gpu):
+    from nbody_amd import EngineError
+    b = physics.uniform_cube(100, seed=1)
+    with Engine(mode="tree") as e:
+        e.upload(b.pos, b.vel, b.mass)
+        with pytest.raises(EngineError):
+            e.shard_advance()                 # not prepared
+        e.set_shard(0, 50)
+        with pytest.raises(EngineError):
+            e.step(1)                         # partial shard must use the shard calls
+        with pytest.raises(EngineError):
+            e.set_shard(90, 20)               # outside the body range
+        e.shard_prepare(); e.shard_advance()
+        with pytest.raises(EngineError):
+            e.download()                      # between advance and commit
+        e.shard_commit()
+        with pytest.raises(EngineError):
+            e.shard_commit()
+
+
+@pytest.mark.parametrize("mode,precision,n", [("tree", "f32", 4096), ("tree", "f64", 1001), ("direct", "f32", 4096),
+                                              ("direct", "mixed", 999)])
+def test_two_ranks_on_one_gpu_match_single_engine(gpu, tmp_path, mode, precision, n):
+    """world_size 2 over gloo, both ranks on cuda:0, real engines: each advances half the targets and the
+    halves are all-gathered; the result must equal one engine stepping everything.  The tree walk gives each
+    body its private result whatever wave it sits in, so tree mode must agree bit for bit; the direct sum
+    may split its source range differently for a half-size launch (summation order), hence a tolerance."""
+    res = run_ranks(tmp_path, 2, [mode, str(n), "3", "gpu", precision], timeout=240)
+    assert np.array_equal(res[0]["pos"], res[1]["pos"]) and np.array_equal(res[0]["vel"], res[1]["vel"])
+    b = physics.makebodies(n - 2, seed=11)
+    with Engine(mode=mode, precision=precision, theta=0.5) as e:
+        e.upload(b.pos, b.vel, b.mass)
+        e.step(3)
+        p, v, m, ids = e.download()
+    if mode == "tree":
+        assert np.array_equal(res[0]["pos"], p) and np.array_equal(res[0]["vel"], v)
+    else:
+        assert np.abs(res[0]["pos"] - p).max() <= 1e-6 * np.abs(p).max()
+        assert np.abs(res[0]["vel"] - v).max() <= 1e-5 * np.abs(v).max()

@@ -1,0 +1,261 @@
+"""Barnes-Hut path on the GPU (Morton sort, octree build, wave-coherent walk) against the CPU oracle,
+through the C ABI.
+
+Oracle configuration for parity: the line-faithful pointer octree of tree.go with the centre of mass
+computed as the mass-weighted mean (`com_mode="true"`; the reference's running update tree.go:189-193 is
+not a centre of mass, see test_reference_com_mode_*), all bodies walked (the reference leaves out the last
+N mod 4, main.go:136-147), depth capped at 21 like the GPU keys.  Tolerances, relative error of the
+acceleration vector per body:
+  fp64 engine vs oracle on the same inputs:          max <= 1e-10 (summation order, fp64 COM reduction)
+  fp32 / mixed engine vs oracle on rounded inputs:   median <= 1e-6, p99.9 <= 1e-3 (opening decisions taken
+                                                     in fp32 can flip next to the threshold)
+Tree vs fp64 direct sum (the physical truth), measured bands: theta = 0.5 median <= 1e-2; theta = 1
+median <= 6e-2."""
+import numpy as np
+import pytest
+
+from nbody_amd import Engine, physics
+from oracle import oracle as O
+from tests.util import f32, golden_cases, load_golden, relerr
+
+pytestmark = pytest.mark.gpu
+G = load_golden()
+CASES = golden_cases(G)
+
+
+def oracle_tree_acc(mass, pos, theta, com_mode="true"):
+    f, alive, st = O.forces(mass, pos, mode="tree", com_mode=com_mode, theta=theta, drop_tail=False, max_depth=21)
+    return f / mass[:, None], alive, st
+
+
+def run_engine(pos, vel, mass, precision, theta, **kw):
+    with Engine(mode="tree", precision=precision, theta=theta, **kw) as e:
+        e.upload(pos, vel, mass)
+        acc, alive = e.accel()
+        return acc, alive, e.stats(), e.tree_nodes()
+
+
+def check(acc, ref, precision):
+    er = relerr(acc, ref)
+    if precision == "f64":
+        assert er.max() <= 1e-10, er.max()
+    else:
+        assert np.median(er) <= 1e-6 and np.quantile(er, 0.999) <= 1e-3, (np.median(er), np.quantile(er, 0.999))
+
+
+@pytest.mark.parametrize("name", CASES)
+@pytest.mark.parametrize("theta", [1.0, 0.5])
+@pytest.mark.parametrize("precision", ["f32", "mixed", "f64"])
+def test_accel_matches_golden_tree_forces(gpu, name, theta, precision):
+    mass, pos, vel = G[f"{name}/mass"], G[f"{name}/pos"], G[f"{name}/vel"]
+    acc, alive, st, _ = run_engine(pos, vel, mass, precision, theta)
+    assert alive.all()
+    if precision == "f64":
+        ref = G[f"{name}/tree_true_th{theta}_all_force"] / mass[:, None]
+        assert relerr(acc, ref).max() <= 1e-10
+        assert st.interactions == int(G[f"{name}/tree_true_th{theta}_all_meta"][0])
+    else:
+        ref, _, ost = oracle_tree_acc(f32(mass), f32(pos), theta)
+        check(acc, ref, precision)
+        assert abs(int(st.interactions) - ost.interactions) <= max(2, 1e-3 * ost.interactions)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 63, 64, 65, 257, 1000, 4096, 20000])
+@pytest.mark.parametrize("precision", ["f32", "f64"])
+def test_ragged_sizes_uniform_cloud(gpu, n, precision):
+    rng = np.random.default_rng(100 + n)
+    pos = rng.uniform(-1e4, 1e4, (n, 3)); mass = np.abs(rng.normal(1e3, 500, n)) + 1
+    if precision != "f64":
+        pos, mass = f32(pos), f32(mass)
+    acc, alive, st, nodes = run_engine(pos, np.zeros((n, 3)), mass, precision, 0.5)
+    ref, _, ost = oracle_tree_acc(mass, pos, 0.5)
+    assert alive.all() and st.n_alive == n
+    if n == 1:
+        assert np.all(acc == 0) and st.tree_nodes == 1 and st.tree_cells == 0
+        return
+    check(acc, ref, precision)
+    if precision == "f64":
+        assert st.interactions == ost.interactions
+
+
+def test_empty_body_set(gpu):
+    with Engine(mode="tree") as e:
+        e.upload(np.zeros((0, 3)), np.zeros((0, 3)), np.zeros(0))
+        e.step(2)
+        assert e.download()[0].shape == (0, 3) and e.tree_nodes().shape == (0, 6)
+
+
+@pytest.mark.parametrize("kind", ["uniform", "galaxy", "plummer"])
+def test_tree_structure_matches_pointer_octree(gpu, kind):
+    """Cell set, masses and centres of mass of the GPU tree against the restatement's pointer octree: the
+    GPU's branching cells are exactly the pointer tree's internal nodes with >= 2 non-empty children, in
+    the same pre-order; leaves are the bodies in the same order."""
+    n = 3000
+    b = {"uniform": physics.uniform_cube, "galaxy": physics.makebodies, "plummer": physics.plummer}[kind](n, seed=4)
+    with Engine(mode="tree", precision="f64", theta=0.5) as e:
+        e.upload(b.pos, b.vel, b.mass)
+        nodes = e.tree_nodes()
+        st = e.stats()
+    dump, alive = O.tree_dump(b.mass, b.pos, com_mode="true", max_depth=21)
+    keep = dump[(dump["kind"] == 0) | (dump["nchild"] >= 2)]      # leaves + branching cells, pre-order kept
+    assert len(keep) == len(nodes) == st.tree_nodes
+    is_cell = nodes[:, 4] > 0
+    assert is_cell.sum() == st.tree_cells == (keep["kind"] == 1).sum()
+    assert np.array_equal(is_cell, keep["kind"] == 1)
+    assert np.array_equal(nodes[:, 4], np.where(keep["kind"] == 1, keep["width"], 0.0))
+    assert np.allclose(nodes[:, 3], keep["mass"], rtol=1e-13, atol=0)
+    assert np.abs(nodes[:, :3] - np.stack([keep["com"][:, k] for k in range(3)], 1)).max() <= 1e-9
+    # leaves appear in the pointer tree's depth-first order
+    leaf_pos = nodes[~is_cell, :3]
+    assert np.array_equal(leaf_pos, b.pos[keep["particle"][keep["kind"] == 0]])
+    # skip pointers: a leaf skips to the next node; the root cell skips to the end
+    assert np.array_equal(nodes[~is_cell, 5], np.nonzero(~is_cell)[0] + 1)
+    assert nodes[0, 5] == len(nodes) and nodes[0, 3] == pytest.approx(b.mass.sum(), rel=1e-13)
+
+
+def test_bodies_outside_the_bound_are_removed(gpu):
+    """tree.go:148-150, 290-292 and main.go:91-95: out-of-bound and NaN bodies leave the simulation; the
+    frame copy holds the survivors in their original order."""
+    rng = np.random.default_rng(8)
+    n = 500
+    pos = rng.uniform(-3e4, 3e4, (n, 3)); mass = np.full(n, 1e5); vel = np.zeros((n, 3))
+    pos[7] = [40000.0, 0, 0]; pos[100] = [0, -32768.5, 0]; pos[101] = [0, -32768.0, 0]; pos[250] = [0, 0, 32768.0]
+    pos[499] = [np.nan, 0, 0]
+    ids = np.arange(1000, 1000 + n, dtype=np.uint64)
+    for precision in ("f32", "f64"):
+        p_in = f32(pos) if precision == "f32" else pos
+        with Engine(mode="tree", precision=precision, theta=0.5) as e:
+            e.upload(p_in, vel, mass, ids)
+            acc, alive = e.accel()
+            ref, oalive, _ = oracle_tree_acc(mass, p_in, 0.5)
+            assert np.array_equal(alive, oalive) and list(np.nonzero(alive == 0)[0]) == [7, 100, 250, 499]
+            assert np.all(acc[alive == 0] == 0)
+            check(acc[alive == 1], ref[alive == 1], precision)
+            e.step(1)
+            p, v, m, got_ids = e.download()
+            assert len(p) == n - 4 and list(got_ids) == [i for i in ids if i - 1000 not in (7, 100, 250, 499)]
+            assert e.stats().n_alive == n - 4
+
+
+def test_body_drifting_out_is_removed_at_the_next_build(gpu):
+    pos = np.array([[32000.0, 0, 0], [0.0, 0, 0], [100.0, 50, 0]]); vel = np.array([[1.0, 0, 0], [0, 0, 0], [0, 0, 0]])
+    with Engine(mode="tree", precision="f64", dt=1000.0) as e:
+        e.upload(pos, vel, np.array([1.0, 1e6, 1e6]))
+        e.step(1)
+        assert len(e.download()[0]) == 3          # moved to x ~ 33000 > 32768 but removal happens in maketree
+        e.step(1)
+        p, v, m, ids = e.download()
+        assert list(ids) == [1, 2]
+
+
+def test_coincident_and_very_close_bodies(gpu):
+    """Depth is capped at 21 levels: bodies sharing a depth-21 cell (here: identical coordinates and a pair
+    1e-3 m apart) become leaves of one cell.  A pair at distance 0 exerts no mutual force (the reference
+    yields NaN there); everything else must match the depth-capped oracle."""
+    rng = np.random.default_rng(2)
+    n = 300
+    pos = rng.uniform(-5e3, 5e3, (n, 3)); mass = np.full(n, 1e4)
+    pos[11] = pos[10]; pos[12] = pos[10]
+    pos[21] = pos[20] + [1e-3, 0, 0]
+    acc, alive, st, nodes = run_engine(pos, np.zeros((n, 3)), mass, "f64", 0.5)
+    assert alive.all() and np.isfinite(acc).all()
+    ref, _, _ = oracle_tree_acc(mass, pos, 0.5)
+    ok = np.ones(n, bool); ok[[10, 11, 12]] = False
+    assert relerr(acc[ok], ref[ok]).max() <= 1e-10
+    others = np.ones(n, bool); others[[10, 11, 12]] = False
+    # the coincident three feel what a lone body there would feel from everyone else
+    lone, _, _ = oracle_tree_acc(mass[others | (np.arange(n) == 10)], pos[others | (np.arange(n) == 10)], 0.5)
+    assert np.allclose(acc[10], acc[11]) and np.allclose(acc[10], acc[12])
+    assert relerr(acc[10:11], lone[10:11]).max() <= 0.05
+
+
+def test_reference_com_mode_is_close_only_when_cores_dominate(gpu):
+    """The reference's centre-of-mass update (tree.go:189-193) omits the rescaling of the old value.  On the
+    default scene (two 1e10 kg cores, main.go:35-36) the forces still agree with the engine to ~1e-4 because
+    the cores are single-body leaves; on a cloud without dominating bodies they do not."""
+    b = physics.makebodies(1000, seed=1)
+    acc, _, _, _ = run_engine(b.pos, b.vel, b.mass, "f64", 1.0)
+    ref_bug, _, _ = oracle_tree_acc(b.mass, b.pos, 1.0, com_mode="ref")
+    assert np.median(relerr(acc, ref_bug)) <= 1e-3
+    u = physics.uniform_cube(1000, seed=1)
+    acc, _, _, _ = run_engine(u.pos, u.vel, u.mass, "f64", 1.0)
+    ref_bug, _, _ = oracle_tree_acc(u.mass, u.pos, 1.0, com_mode="ref")
+    direct = O.direct_rows(u.mass, u.pos) / u.mass[:, None]
+    assert np.median(relerr(ref_bug, direct)) > 0.5          # the reference itself is far from the truth here
+    assert np.median(relerr(acc, direct)) <= 6e-2
+
+
+@pytest.mark.parametrize("theta,median_tol,p90_tol", [(1.0, 6e-2, 0.2), (0.5, 1e-2, 3e-2)])
+def test_tree_against_fp64_direct_sum(gpu, theta, median_tol, p90_tol):
+    b = physics.plummer(8192, seed=6)
+    acc, _, _, _ = run_engine(b.pos, b.vel, b.mass, "f32", theta)
+    direct = O.direct_rows(b.mass, b.pos) / b.mass[:, None]
+    er = relerr(acc, direct)
+    assert np.median(er) <= median_tol and np.quantile(er, 0.9) <= p90_tol
+
+
+def test_default_scene_100_steps(gpu):
+    """BASELINE config 1: main.go's default galaxy pair (1000 + 2 bodies, theta = 1, dt = 3600), 100 steps,
+    fp64 engine against the oracle's tree path (true COM, all bodies walked)."""
+    b = physics.makebodies(1000, seed=1)
+    with Engine(mode="tree", precision="f64", theta=1.0) as e:
+        e.upload(b.pos, b.vel, b.mass)
+        e.step(100)
+        p, v, m, ids = e.download()
+    pr, vr, alive, _ = O.step(b.mass, b.pos, b.vel, nsteps=100, mode="tree", com_mode="true", theta=1.0,
+                              drop_tail=False, max_depth=21)
+    # bodies flung out of the bound by unsoftened close passes are removed by both, at the same step
+    assert np.array_equal(ids.astype(np.int64), np.nonzero(alive)[0]) and len(ids) >= 950
+    sel = ids.astype(np.int64)
+    assert np.abs(p - pr[sel]).max() <= 1e-6 * np.abs(pr[sel]).max()
+    assert np.abs(v - vr[sel]).max() <= 1e-5 * np.abs(vr[sel]).max()
+
+
+@pytest.mark.parametrize("name", CASES)
+@pytest.mark.parametrize("precision,tol,median_tol", [("f64", 1e-10, 1e-14), ("mixed", 5e-5, 1e-7), ("f32", 1e-4, 2e-6)])
+def test_ten_steps_match_golden(gpu, name, precision, tol, median_tol):
+    """Ten tree steps (theta = 0.5) against the oracle's (true COM, all bodies walked).  Bodies flung out of
+    the 2^16 m bound by an unsoftened close pass are removed by both (tree.go:290-292); survivors are matched
+    by ID.  Error metric as in the direct-sum step test."""
+    mass, pos, vel = G[f"{name}/mass"], G[f"{name}/pos"], G[f"{name}/vel"]
+    with Engine(mode="tree", precision=precision, theta=0.5) as e:
+        e.upload(pos, vel, mass)
+        e.step(10)
+        p, v, m, ids = e.download()
+    pr, vr = G[f"{name}/step10_tree_true_pos"], G[f"{name}/step10_tree_true_vel"]
+    inside = (np.abs(pr) < 32768).all(1)
+    assert len(ids) >= inside.sum() - 1 and np.all(np.diff(ids.astype(np.int64)) > 0)
+    sel = ids.astype(np.int64)
+    ep = np.abs(p - pr[sel]).max(1) / np.abs(pr).max()
+    ev = np.abs(v - vr[sel]).max(1) / np.abs(vr).max()
+    assert ep.max() <= tol and ev.max() <= 10 * tol
+    assert np.median(ep) <= median_tol and np.median(ev) <= 10 * median_tol
+
+
+def test_1m_plummer_properties(gpu):
+    """BASELINE config 3 size (1,048,576-body Plummer sphere, theta = 0.5): size-independent checks.
+    (a) every body survives and keeps its identity through the Morton reordering (ids and masses);
+    (b) tree accelerations agree with the GPU's own fp32 direct sum: median <= 1e-2, p99 <= 6e-2;
+    (c) node bookkeeping: nodes = bodies + cells, cells < bodies;
+    (d) a sample of bodies agrees with the CPU oracle's tree walk (fp32 tolerances)."""
+    n = 1 << 20
+    b = physics.plummer(n, seed=3)
+    pos, mass = f32(b.pos), f32(b.mass)
+    with Engine(mode="tree", precision="f32", theta=0.5) as e:
+        e.upload(pos, b.vel, mass)
+        acc, alive = e.accel()
+        st = e.stats()
+        e.step(2)
+        p, v, m, ids = e.download()
+    assert alive.all() and st.n_alive == n and st.tree_nodes == n + st.tree_cells and 0 < st.tree_cells < n
+    assert np.array_equal(ids, np.arange(n, dtype=np.uint64)) and np.array_equal(m, mass)
+    assert np.isfinite(p).all() and np.abs(p - pos).max() < 500.0
+    with Engine(mode="direct", precision="f32") as e:
+        e.upload(pos, b.vel, mass)
+        dacc, _ = e.accel()
+    er = relerr(acc, dacc)
+    assert np.median(er) <= 1e-2 and np.quantile(er, 0.99) <= 6e-2
+    ref, _, ost = oracle_tree_acc(mass, pos, 0.5)
+    sample = np.arange(0, n, 997)
+    check(acc[sample], ref[sample], "f32")
+    assert abs(int(st.interactions) - ost.interactions) <= 1e-4 * ost.interactions
