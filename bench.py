@@ -1,0 +1,232 @@
+#!/usr/bin/env python3
+"""Benchmark of the gravity engine's hot path (one step = force pass + fused kick-drift over all bodies).
+
+Contract: `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched by torch.distributed.run
+with one rank per GPU.  W untimed steps, then exactly K timed steps bracketed by barrier + device
+synchronisation, maximum over ranks, and rank 0 prints ONE JSON line on stdout (everything else goes to stderr).
+
+Headline workload (config.workload = "direct_fp32_plummer_1M"): 1,048,576-body Plummer sphere, fp32 tiled
+direct sum; value = body-body interactions per second (ordered pairs N*(N-1) per step) over the whole job.
+With N GPUs the targets are sharded and positions/velocities all-gathered each step, total work fixed
+("strong" scaling).  Extra, untimed-region results ride along in "extra": the Barnes-Hut path on the same
+cloud (theta = 0.5) at 1M bodies, and at 16M bodies when N > 1.
+
+"roofline": dominant kernel of the headline = the direct-sum force kernel; bound = fp32 vector ALU
+(157.3 TFLOP/s); achieved = interactions * 20 flop / mean kernel time, timed live with HIP events on the
+engine's stream.  "cpu_baseline": the CPU oracle (a C port of the reference's loops; the Go reference cannot be
+built here) on a bounded sample, rank 0 at N = 1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FLOP_PER_INTERACTION = 20          # 3 sub, 3 mul/fma (r^2), 1 rsqrt, 3 mul (m/r^3), 3 fma, rounded up as customary
+FP32_VALU_PEAK_TFLOPS = 157.3      # MI355X vector fp32 peak
+HBM_PEAK_GBS = 8000.0
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--bodies", type=int, default=1 << 20, help="bodies of the headline workload")
+    ap.add_argument("--workload", default="direct", choices=["direct", "tree"], help="path timed as the headline")
+    ap.add_argument("--no-extra", action="store_true", help="skip the Barnes-Hut extras")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=65536, help="bodies of the CPU direct-sum sample")
+    return ap.parse_args()
+
+
+def timed_steps(step_fn, sync_fn, barrier_fn, warmup, steps):
+    for _ in range(warmup):
+        step_fn()
+    sync_fn(); barrier_fn(); sync_fn()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step_fn()
+    sync_fn(); barrier_fn()
+    return time.perf_counter() - t0
+
+
+def traffic_from_profiles(workload):
+    """HBM bytes per launch of the dominant kernel, taken from the committed rocprofv3 --pmc passes
+    (profiles/traffic.json, written by profiles/collect.sh); None if not collected for this workload."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f).get(workload, {}).get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
+def cpu_baseline_direct(sample):
+    """The reference's direct path (serial i<j pair loop, main.go:107-128) as ported in oracle/nbody_oracle.c,
+    one thread, on `sample` bodies drawn from the same Plummer cloud."""
+    from nbody_amd import physics
+    from oracle import oracle as O
+    b = physics.plummer(sample, seed=1)
+    t0 = time.perf_counter()
+    _, _, st = O.forces(b.mass, b.pos, mode="direct")
+    dt = time.perf_counter() - t0
+    return {"value": st.interactions / dt, "unit": "interactions/s", "cores": 1, "kind": "port",
+            "sample": f"direct pair loop of main.go:107-128 (C port, fp64, 1 thread as in the reference) on "
+                      f"{sample} bodies of the same Plummer cloud, one force pass, {dt:.1f} s"}
+
+
+def cpu_baseline_tree(n, theta):
+    """The reference's tree path: serial octree build + 4 walk threads (main.go:133-149), C port, true-COM mode."""
+    from nbody_amd import physics
+    from oracle import oracle as O
+    b = physics.plummer(n, seed=1)
+    t0 = time.perf_counter()
+    _, _, st = O.forces(b.mass, b.pos, mode="tree", com_mode="true", theta=theta, drop_tail=False, groups=4)
+    dt = time.perf_counter() - t0
+    return {"steps_per_s": 1.0 / dt, "interactions_per_s": st.interactions / dt, "cores": 4, "kind": "port",
+            "build_s": st.build_seconds, "walk_s": st.walk_seconds,
+            "sample": f"one force pass on {n} bodies, theta={theta}, serial build + 4 walk threads"}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    from nbody_amd import Engine, physics
+    from nbody_amd.sharded import EngineShard, ShardedStepper
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        log(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}; using WORLD_SIZE")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    def sync():
+        torch.cuda.synchronize()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    def run(mode, n, precision, theta, steps, warmup, seed=1):
+        b = physics.plummer(n, seed=seed)
+        eng = Engine(mode=mode, precision=precision, theta=theta, device=local)
+        eng.upload(b.pos, b.vel, b.mass)
+        del b
+        if world > 1:
+            stepper = ShardedStepper(EngineShard(eng, device_index=local))
+            step_fn = stepper.step
+        else:
+            eng.set_stream(torch.cuda.current_stream().cuda_stream)
+            step_fn = eng.step
+        sec = timed_steps(step_fn, sync, barrier, warmup, steps)
+        if world > 1:
+            t = torch.tensor([sec], device="cuda", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            sec = float(t.item())
+        return eng, sec
+
+    n = args.bodies
+    headline_mode = args.workload
+    eng, sec = run(headline_mode, n, "f32", 0.5, args.steps, args.warmup)
+    # dominant kernel, timed with HIP events on the engine's stream (this rank's shard)
+    kernel_ms = eng.time_force_kernel(3)
+    st = eng.stats()
+    if headline_mode == "direct":
+        inter_per_step = n * (n - 1)
+        kernel_inter = st.interactions
+        workload = f"direct_fp32_plummer_{n >> 20}M" if n % (1 << 20) == 0 else f"direct_fp32_plummer_{n}"
+    else:
+        full = st.interactions
+        if world > 1:
+            t = torch.tensor([float(full)], device="cuda", dtype=torch.float64)
+            dist.all_reduce(t)
+            full = float(t.item())
+        inter_per_step = full
+        kernel_inter = st.interactions
+        workload = f"bh_theta0.5_fp32_plummer_{n >> 20}M" if n % (1 << 20) == 0 else f"bh_theta0.5_fp32_plummer_{n}"
+    value = inter_per_step * args.steps / sec
+    achieved = kernel_inter * FLOP_PER_INTERACTION / (kernel_ms * 1e-3) / 1e12
+    roofline = {"bound": "valu", "kernel": "direct_kernel<float,float,4>" if headline_mode == "direct" else "walk_kernel<float>",
+                "achieved": achieved, "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_VALU_PEAK_TFLOPS,
+                "traffic": traffic_from_profiles(workload), "kernel_ms": kernel_ms,
+                "flop_per_interaction": FLOP_PER_INTERACTION}
+    eng.close()
+
+    extra = {}
+    if not args.no_extra:
+        other = "tree" if headline_mode == "direct" else "direct"
+        m = 1 << 20
+        e2, s2 = run(other, m, "f32", 0.5, max(args.steps, 10), max(args.warmup, 2))
+        st2 = None
+        if world == 1:
+            st2 = e2.step_timed()
+        kms = e2.time_force_kernel(3)
+        s_inter = e2.stats().interactions
+        if world > 1:
+            t = torch.tensor([float(s_inter)], device="cuda", dtype=torch.float64)
+            dist.all_reduce(t)
+            s_inter = float(t.item())
+        key = "bh_theta0.5_fp32_plummer_1M" if other == "tree" else "direct_fp32_plummer_1M"
+        extra[key] = {"steps_per_s": max(args.steps, 10) / s2, "ms_per_step": 1e3 * s2 / max(args.steps, 10),
+                      "interactions_per_step": s_inter, "interactions_per_s": s_inter * max(args.steps, 10) / s2,
+                      "force_kernel_ms": kms,
+                      "force_kernel_frac_of_fp32_valu_peak": (s_inter / world) * FLOP_PER_INTERACTION / (kms * 1e-3) / 1e12 / FP32_VALU_PEAK_TFLOPS}
+        if st2 is not None:
+            nb = m
+            extra[key].update({"ms_sort": st2.ms_sort, "ms_build": st2.ms_build, "ms_force": st2.ms_force,
+                               "tree_nodes": int(st2.tree_nodes),
+                               "sort_algorithmic_GBps": nb * 200.0 / (st2.ms_sort * 1e-3) / 1e9 if st2.ms_sort > 0 else None,
+                               "build_algorithmic_GBps": nb * 130.0 / (st2.ms_build * 1e-3) / 1e9 if st2.ms_build > 0 else None})
+        e2.close()
+        if world > 1:
+            m = 1 << 24
+            e3, s3 = run("tree", m, "f32", 0.5, 5, 1)
+            i3 = e3.stats().interactions
+            t = torch.tensor([float(i3)], device="cuda", dtype=torch.float64)
+            dist.all_reduce(t)
+            extra["bh_theta0.5_fp32_plummer_16M"] = {"steps_per_s": 5 / s3, "ms_per_step": 1e3 * s3 / 5,
+                                                     "interactions_per_s": float(t.item()) * 5 / s3}
+            e3.close()
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline_direct(args.cpu_sample) if headline_mode == "direct" else None
+        try:
+            tb = cpu_baseline_tree(1 << 20, 0.5)
+            if headline_mode == "tree":
+                cpu = {"value": tb["interactions_per_s"], "unit": "interactions/s", "cores": 4, "kind": "port", "sample": tb["sample"]}
+            extra["cpu_tree_path_1M"] = tb
+        except Exception as ex:  # the baseline must never take the benchmark down
+            log("cpu tree baseline failed:", ex)
+
+    if rank == 0:
+        out = {"metric": "body-body interactions/sec", "value": value, "unit": "interactions/s", "n_gpus": world,
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * sec / args.steps, "steps_per_s": args.steps / sec,
+               "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": workload, "bodies": n, "ic": "Plummer sphere a=2e3 m, M=1e9 kg, seed 1",
+                          "dt": 3600.0, "eps": 0.0, "parallelism": f"targets sharded over {world} GPU(s), all-gather of pos+vel per step" if world > 1 else "single GPU"},
+               "roofline": roofline, "cpu_baseline": cpu, "extra": extra}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,22 @@
+#!/bin/bash
+# Collects the rocprofv3 evidence behind bench.py's numbers.  Run on the GPU box from the repository root:
+#   bash profiles/collect.sh r01
+# Pass 1: kernel trace + stats of the default bench command.  Passes 2 and 3: HBM traffic counters of the
+# headline direct-sum run and of the Barnes-Hut run, each counter group in a run of its own (no tracing
+# domains together with --pmc).  Outputs land in gpurun_out/prof_<tag>/ ; summarise.py condenses them into
+# profiles/<tag>_*.txt and profiles/traffic.json, which are the files that get committed.
+set -u
+TAG=${1:-r01}
+OUT=gpurun_out/prof_$TAG
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+run() { echo "== $*" >&2; timeout -s KILL "$@"; }
+run 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/bench_trace.json" 2> "$OUT/bench_trace.err" || exit 1
+run 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch_direct" -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extra > /dev/null 2> "$OUT/pmc1.err" || exit 1
+run 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write_direct" -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extra > /dev/null 2> "$OUT/pmc2.err" || exit 1
+run 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch_tree" -- python3 bench.py --workload tree --steps 2 --warmup 1 --no-cpu-baseline --no-extra > /dev/null 2> "$OUT/pmc3.err" || exit 1
+run 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write_tree" -- python3 bench.py --workload tree --steps 2 --warmup 1 --no-cpu-baseline --no-extra > /dev/null 2> "$OUT/pmc4.err" || exit 1
+run 300 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d "$OUT/pmc_sq_direct" -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extra > /dev/null 2> "$OUT/pmc5.err" || exit 1
+run 300 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAIT_INST_ANY --output-format csv -d "$OUT/pmc_sq_tree" -- python3 bench.py --workload tree --steps 2 --warmup 1 --no-cpu-baseline --no-extra > /dev/null 2> "$OUT/pmc6.err" || exit 1
+find "$OUT" -name "*.csv" | head -40 >&2
+python3 profiles/summarise.py "$TAG"

@@ -1,0 +1,81 @@
+"""Condenses the rocprofv3 CSVs under gpurun_out/prof_<tag>/ into the committed summaries:
+profiles/<tag>_kernel_stats.txt (per-kernel calls / total / average duration), profiles/<tag>_pmc.txt
+(counter totals per kernel) and profiles/traffic.json (HBM bytes per launch of each dominant kernel).
+
+HBM bytes follow the gfx950 rule that FETCH_SIZE reports half the bytes of a wide coalesced streaming read:
+bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 per launch (both counters are in KiB)."""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+base = os.path.join(root, "gpurun_out", f"prof_{tag}")
+
+
+def rows(pattern):
+    for path in glob.glob(os.path.join(base, pattern), recursive=True):
+        with open(path, newline="") as f:
+            for r in csv.DictReader(f):
+                yield r
+
+
+def short(name):
+    name = name.split("(")[0]
+    for k in ("direct_kernel", "direct_finish_kernel", "walk_kernel", "radix_scatter_kernel", "radix_hist_kernel",
+              "scan_reduce_kernel", "scan_sums_kernel", "scan_apply_kernel", "keys_kernel", "permute_kernel",
+              "radix_tree_kernel", "mark_cells_kernel", "emit_nodes_kernel", "cell_mass_kernel", "carry_dead_kernel",
+              "refresh_mirror_kernel", "kinetic_kernel", "potential_kernel"):
+        if k in name:
+            return k
+    return name[:60]
+
+
+# ---- kernel trace ----
+agg = defaultdict(lambda: [0, 0.0, 1e30, 0.0])
+for r in rows("trace/**/*kernel_trace.csv"):
+    d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3   # us
+    a = agg[short(r["Kernel_Name"])]
+    a[0] += 1; a[1] += d; a[2] = min(a[2], d); a[3] = max(a[3], d)
+total = sum(a[1] for a in agg.values()) or 1.0
+with open(os.path.join(root, "profiles", f"{tag}_kernel_stats.txt"), "w") as f:
+    f.write(f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline   (tag {tag})\n")
+    f.write(f"{'kernel':28s} {'calls':>7s} {'total_us':>14s} {'avg_us':>12s} {'min_us':>12s} {'max_us':>12s} {'share':>7s}\n")
+    for k, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        f.write(f"{k:28s} {a[0]:7d} {a[1]:14.1f} {a[1] / a[0]:12.2f} {a[2]:12.2f} {a[3]:12.2f} {100 * a[1] / total:6.2f}%\n")
+
+# ---- counters ----
+pmc = defaultdict(lambda: defaultdict(lambda: [0, 0.0]))
+for sub in ("pmc_fetch_direct", "pmc_write_direct", "pmc_fetch_tree", "pmc_write_tree", "pmc_sq_direct", "pmc_sq_tree"):
+    for r in rows(f"{sub}/**/*counter_collection.csv"):
+        a = pmc[sub][(short(r["Kernel_Name"]), r["Counter_Name"])]
+        a[0] += 1; a[1] += float(r["Counter_Value"])
+with open(os.path.join(root, "profiles", f"{tag}_pmc.txt"), "w") as f:
+    f.write(f"# rocprofv3 --pmc passes (one counter group per run), tag {tag}; value = mean per dispatch\n")
+    for sub in sorted(pmc):
+        f.write(f"\n[{sub}]\n")
+        for (k, c), a in sorted(pmc[sub].items()):
+            f.write(f"{k:28s} {c:24s} dispatches {a[0]:6d}  mean {a[1] / a[0]:18.1f}\n")
+
+
+def mean(sub, kernel, counter):
+    a = pmc.get(sub, {}).get((kernel, counter))
+    return a[1] / a[0] if a and a[0] else None
+
+
+traffic = {}
+for workload, kernel, fs, ws in (("direct_fp32_plummer_1M", "direct_kernel", "pmc_fetch_direct", "pmc_write_direct"),
+                                 ("bh_theta0.5_fp32_plummer_1M", "walk_kernel", "pmc_fetch_tree", "pmc_write_tree")):
+    fe, wr = mean(fs, kernel, "FETCH_SIZE"), mean(ws, kernel, "WRITE_SIZE")
+    if fe is not None and wr is not None:
+        traffic[workload] = {"kernel": kernel, "FETCH_SIZE_KiB": fe, "WRITE_SIZE_KiB": wr,
+                             "hbm_bytes_per_launch": (2 * fe + wr) * 1024, "tag": tag,
+                             "rule": "(2*FETCH_SIZE + WRITE_SIZE) * 1024: gfx950 FETCH_SIZE counts half of a wide coalesced read"}
+if traffic:
+    with open(os.path.join(root, "profiles", "traffic.json"), "w") as f:
+        json.dump(traffic, f, indent=1)
+print(open(os.path.join(root, "profiles", f"{tag}_kernel_stats.txt")).read())
+print(json.dumps(traffic, indent=1))
