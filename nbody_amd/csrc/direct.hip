@@ -5,18 +5,55 @@
 // along (xj-xi)/r and divides by mi in update; here the acceleration a_i = G * sum_j mj*(xj-xi)/r^3 is
 // accumulated directly, which is the same quantity up to rounding.
 //
-// Layout: each 256-thread workgroup owns 256*ITILE targets held in registers and streams the sources
-// through LDS in tiles of 256 (one 16- or 32-byte element per thread per tile, read back as broadcast
-// ds_read_b128).  Per source the inner loop spends 3 sub, 3 fma (r^2), 1 rsq, 3 mul, 3 fma per target.
+// Layout: each workgroup owns BLOCK*ITILE targets held in registers and streams the sources through LDS
+// in tiles of 256 (16- or 32-byte elements, read back as broadcast ds_read_b128).  Per source and target
+// the inner loop spends 3 sub, 3 fma (r^2), 1 rsq, 3 mul, 3 fma.
 // The self term and padded sources contribute exactly 0: r^2 carries a floor (eps^2 or a tiny constant)
 // so rsq stays finite and is multiplied by dx = 0 or m = 0.
 #include "engine_internal.h"
 #include "kernels_common.h"
 
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+
+#define DIRECT_TILE 256   // sources per LDS tile
+
+// Per-lane target state and the tile loop of the generic (scalar arithmetic) kernel; fp64 uses it.
+template <typename R, int ITILE> struct Targets;
+
+template <int ITILE> struct Targets<double, ITILE> {
+    double px[ITILE], py[ITILE], pz[ITILE], gx[ITILE], gy[ITILE], gz[ITILE];
+    __device__ __forceinline__ void set(int k, double x, double y, double z) { px[k] = x; py[k] = y; pz[k] = z; }
+    __device__ __forceinline__ void tile(const double4* sh, double floor2)
+    {
+#pragma unroll
+        for (int k = 0; k < ITILE; k++) { gx[k] = 0; gy[k] = 0; gz[k] = 0; }
+#pragma unroll 4
+        for (int jj = 0; jj < DIRECT_TILE; jj++) {
+            const double4 s = sh[jj];
+#pragma unroll
+            for (int k = 0; k < ITILE; k++) {
+                const double dx = s.x - px[k], dy = s.y - py[k], dz = s.z - pz[k];
+                const double r2 = fma(dx, dx, fma(dy, dy, fma(dz, dz, floor2)));
+                const double rinv = rsq_dev(r2);
+                const double w = (rinv * rinv) * (rinv * s.w);
+                gx[k] = fma(dx, w, gx[k]); gy[k] = fma(dy, w, gy[k]); gz[k] = fma(dz, w, gz[k]);
+            }
+        }
+    }
+    __device__ __forceinline__ double sum_x(int k) const { return gx[k]; }
+    __device__ __forceinline__ double sum_y(int k) const { return gy[k]; }
+    __device__ __forceinline__ double sum_z(int k) const { return gz[k]; }
+};
+
 // R: type of the pair arithmetic; A: type of the running sums and of the state (A == R, or R = float with
-// A = double).  Each 256-source tile is summed in R and the tile sums are accumulated in A.
-template <typename R, typename A, int ITILE, int OUT>
-__global__ __launch_bounds__(256) void direct_kernel(
+// A = double).  Each 256-source tile is summed in R and the tile sums are accumulated in A, which keeps
+// fp32 rounding growth at ~sqrt(256) + sqrt(N/256) ulps instead of ~sqrt(N).
+// BLOCK threads own BLOCK*ITILE targets (lane t: targets ibase + k*BLOCK + t).  fp32 runs one wave per
+// workgroup: the waves of a CU then drift apart instead of meeting at a barrier every tile, which measured
+// 5 % faster than 256-thread workgroups.
+template <typename R, typename A, int ITILE, int BLOCK, int OUT>
+__global__ __launch_bounds__(BLOCK) void direct_kernel(
     const typename V4<R>::type* __restrict__ src, int n_src, int t0, int t1, int jchunk, R floor2, A G, A dt,
     typename V4<A>::type* __restrict__ acc_out,
     const typename V4<A>::type* __restrict__ pos_in, const typename V4<A>::type* __restrict__ vel_in,
@@ -25,60 +62,138 @@ __global__ __launch_bounds__(256) void direct_kernel(
 {
     using R4 = typename V4<R>::type;
     using A4 = typename V4<A>::type;
-    __shared__ R4 sh[256];
+    __shared__ R4 sh[DIRECT_TILE];
     const int tid = threadIdx.x;
-    const int ibase = t0 + blockIdx.x * (256 * ITILE);
+    const int ibase = t0 + blockIdx.x * (BLOCK * ITILE);
 
-    R xi[ITILE], yi[ITILE], zi[ITILE];
+    Targets<R, ITILE> tg;
     A ax[ITILE], ay[ITILE], az[ITILE];
 #pragma unroll
     for (int k = 0; k < ITILE; k++) {
-        int i = ibase + k * 256 + tid;
+        int i = ibase + k * BLOCK + tid;
         if (i > t1 - 1) i = t1 - 1;
-        R4 p = src[i];
-        xi[k] = p.x; yi[k] = p.y; zi[k] = p.z;
+        const R4 p = src[i];
+        tg.set(k, p.x, p.y, p.z);
         ax[k] = 0; ay[k] = 0; az[k] = 0;
     }
 
     const int jb = blockIdx.y * jchunk;
     const int je = (jb + jchunk < n_src) ? jb + jchunk : n_src;
-    R4 pad; pad.x = 0; pad.y = 0; pad.z = 0; pad.w = 0;
-    R4 nxt = pad;
-    if (jb + tid < je) nxt = src[jb + tid];
-
-    for (int jt = jb; jt < je; jt += 256) {
+    for (int jt = jb; jt < je; jt += DIRECT_TILE) {
         __syncthreads();
-        sh[tid] = nxt;
-        __syncthreads();
-        nxt = pad;
-        if (jt + 256 + tid < je) nxt = src[jt + 256 + tid];
-
-        // Sums are blocked: one partial per 256-source tile, added to the running total afterwards.  This
-        // keeps fp32 rounding growth at ~sqrt(256) + sqrt(N/256) ulps instead of ~sqrt(N).
-        R fx[ITILE], fy[ITILE], fz[ITILE];
+        if (jt + DIRECT_TILE <= je) {
 #pragma unroll
-        for (int k = 0; k < ITILE; k++) { fx[k] = 0; fy[k] = 0; fz[k] = 0; }
-#pragma unroll 8
-        for (int jj = 0; jj < 256; jj++) {
-            const R4 s = sh[jj];
+            for (int q = 0; q < DIRECT_TILE / BLOCK; q++) sh[q * BLOCK + tid] = src[jt + q * BLOCK + tid];
+        } else {                                         // last, partial tile: pad with massless sources
 #pragma unroll
-            for (int k = 0; k < ITILE; k++) {
-                R dx = s.x - xi[k], dy = s.y - yi[k], dz = s.z - zi[k];
-                R r2 = fma(dx, dx, fma(dy, dy, fma(dz, dz, floor2)));
-                R rinv = rsq_dev(r2);
-                R w = (rinv * rinv) * (rinv * s.w);
-                fx[k] = fma(dx, w, fx[k]);
-                fy[k] = fma(dy, w, fy[k]);
-                fz[k] = fma(dz, w, fz[k]);
+            for (int q = 0; q < DIRECT_TILE / BLOCK; q++) {
+                const int j = jt + q * BLOCK + tid;
+                R4 v = src[j < je ? j : je - 1];
+                if (j >= je) v.w = 0;
+                sh[q * BLOCK + tid] = v;
             }
         }
+        __syncthreads();
+        tg.tile(sh, floor2);
 #pragma unroll
-        for (int k = 0; k < ITILE; k++) { ax[k] += (A)fx[k]; ay[k] += (A)fy[k]; az[k] += (A)fz[k]; }
+        for (int k = 0; k < ITILE; k++) { ax[k] += (A)tg.sum_x(k); ay[k] += (A)tg.sum_y(k); az[k] += (A)tg.sum_z(k); }
     }
 
 #pragma unroll
     for (int k = 0; k < ITILE; k++) {
-        const int i = ibase + k * 256 + tid;
+        const int i = ibase + k * BLOCK + tid;
+        if (i >= t1) continue;
+        if (OUT == OUT_PARTIAL) {
+            A4 o; o.x = ax[k]; o.y = ay[k]; o.z = az[k]; o.w = 0;
+            acc_out[(size_t)blockIdx.y * (size_t)(t1 - t0) + (size_t)(i - t0)] = o;
+        } else if (OUT == OUT_ACC) {
+            A4 o; o.x = G * ax[k]; o.y = G * ay[k]; o.z = G * az[k]; o.w = 0;
+            acc_out[i] = o;
+        } else {
+            kick_drift<A>(i, G * ax[k], G * ay[k], G * az[k], dt, pos_in, vel_in, pos_out, vel_out, mirror_out);
+        }
+    }
+}
+
+// fp32 pair arithmetic.  Targets are held two to a register pair so that the whole body is packed math
+// (v_pk_add_f32, v_pk_fma_f32, v_pk_mul_f32, the source broadcast through op_sel); only the two v_rsq_f32
+// per pair are scalar.  Measured on MI355X: a packed op issues in 4 cycles per wave and v_rsq_f32 in 8, so a
+// pair of interactions costs 12*4 + 2*8 = 64 cycles; at the sustained clock (2.24-2.30 GHz measured in the
+// kernel) that bounds one GPU at 4.6-4.7e12 interactions/s, and this kernel reaches ~94 % of it.
+// One wave per workgroup (BLOCK = 64): the waves of a CU drift apart instead of meeting at a barrier every
+// tile (+5 % over 256-thread workgroups).  This file is compiled with the max-ILP scheduler strategy (see the
+// Makefile): it interleaves several sources so that no wait states are needed behind v_rsq_f32 (+8 %).
+template <typename A, int ITILE, int BLOCK, int OUT>
+__global__ __launch_bounds__(BLOCK) void direct_kernel_f32(
+    const float4* __restrict__ src, int n_src, int t0, int t1, int jchunk, float floor2, A G, A dt,
+    typename V4<A>::type* __restrict__ acc_out,
+    const typename V4<A>::type* __restrict__ pos_in, const typename V4<A>::type* __restrict__ vel_in,
+    typename V4<A>::type* __restrict__ pos_out, typename V4<A>::type* __restrict__ vel_out,
+    float4* __restrict__ mirror_out)
+{
+    using A4 = typename V4<A>::type;
+    static_assert(ITILE % 2 == 0, "fp32 targets are processed in pairs");
+    __shared__ float4 sh[DIRECT_TILE];
+    const int tid = threadIdx.x;
+    const int ibase = t0 + blockIdx.x * (BLOCK * ITILE);
+
+    f2 xi[ITILE / 2], yi[ITILE / 2], zi[ITILE / 2];
+    A ax[ITILE], ay[ITILE], az[ITILE];
+#pragma unroll
+    for (int p = 0; p < ITILE / 2; p++) {
+        int i0 = ibase + (2 * p) * BLOCK + tid, i1 = i0 + BLOCK;
+        if (i0 > t1 - 1) i0 = t1 - 1;
+        if (i1 > t1 - 1) i1 = t1 - 1;
+        const float4 a = src[i0], b = src[i1];
+        xi[p] = f2{a.x, b.x}; yi[p] = f2{a.y, b.y}; zi[p] = f2{a.z, b.z};
+    }
+#pragma unroll
+    for (int k = 0; k < ITILE; k++) { ax[k] = 0; ay[k] = 0; az[k] = 0; }
+    const f2 fl = {floor2, floor2};
+
+    const int jb = blockIdx.y * jchunk;
+    const int je = (jb + jchunk < n_src) ? jb + jchunk : n_src;
+    for (int jt = jb; jt < je; jt += DIRECT_TILE) {
+        __syncthreads();
+        if (jt + DIRECT_TILE <= je) {
+#pragma unroll
+            for (int q = 0; q < DIRECT_TILE / BLOCK; q++) sh[q * BLOCK + tid] = src[jt + q * BLOCK + tid];
+        } else {                                         // last, partial tile: pad with massless sources
+#pragma unroll
+            for (int q = 0; q < DIRECT_TILE / BLOCK; q++) {
+                const int j = jt + q * BLOCK + tid;
+                float4 v = src[j < je ? j : je - 1];
+                if (j >= je) v.w = 0;
+                sh[q * BLOCK + tid] = v;
+            }
+        }
+        __syncthreads();
+        f2 fx[ITILE / 2], fy[ITILE / 2], fz[ITILE / 2];
+#pragma unroll
+        for (int p = 0; p < ITILE / 2; p++) { fx[p] = 0; fy[p] = 0; fz[p] = 0; }
+#pragma unroll 8
+        for (int jj = 0; jj < DIRECT_TILE; jj++) {
+            const float4 s = sh[jj];
+            const f2 sx = {s.x, s.x}, sy = {s.y, s.y}, sz = {s.z, s.z}, sm = {s.w, s.w};
+#pragma unroll
+            for (int p = 0; p < ITILE / 2; p++) {
+                f2 dx = sx - xi[p], dy = sy - yi[p], dz = sz - zi[p];
+                f2 r2 = fma2(dx, dx, fma2(dy, dy, fma2(dz, dz, fl)));
+                f2 rinv = {__builtin_amdgcn_rsqf(r2.x), __builtin_amdgcn_rsqf(r2.y)};
+                f2 w = (rinv * rinv) * (rinv * sm);
+                fx[p] = fma2(dx, w, fx[p]); fy[p] = fma2(dy, w, fy[p]); fz[p] = fma2(dz, w, fz[p]);
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < ITILE / 2; p++) {
+            ax[2 * p] += (A)fx[p].x; ay[2 * p] += (A)fy[p].x; az[2 * p] += (A)fz[p].x;
+            ax[2 * p + 1] += (A)fx[p].y; ay[2 * p + 1] += (A)fy[p].y; az[2 * p + 1] += (A)fz[p].y;
+        }
+    }
+
+#pragma unroll
+    for (int k = 0; k < ITILE; k++) {
+        const int i = ibase + k * BLOCK + tid;
         if (i >= t1) continue;
         if (OUT == OUT_PARTIAL) {
             A4 o; o.x = ax[k]; o.y = ay[k]; o.z = az[k]; o.w = 0;
@@ -118,7 +233,15 @@ __global__ __launch_bounds__(256) void direct_finish_kernel(
     }
 }
 
-template <typename R, typename A, int ITILE>
+// Picks the packed fp32 kernel or the generic one.
+template <typename R, typename A, int ITILE, int BLOCK, int OUT> struct DirectKernel {
+    static constexpr auto fn() { return &direct_kernel<R, A, ITILE, BLOCK, OUT>; }
+};
+template <typename A, int ITILE, int BLOCK, int OUT> struct DirectKernel<float, A, ITILE, BLOCK, OUT> {
+    static constexpr auto fn() { return &direct_kernel_f32<A, ITILE, BLOCK, OUT>; }
+};
+
+template <typename R, typename A, int ITILE, int BLOCK>
 static int launch_direct(nbe_engine* e, const void* src, uint64_t t0, uint64_t t1, bool fused, int src_buf, int dst_buf)
 {
     using R4 = typename V4<R>::type;
@@ -126,14 +249,15 @@ static int launch_direct(nbe_engine* e, const void* src, uint64_t t0, uint64_t t
     const size_t n = e->n, nt = (size_t)(t1 - t0);
     if (nt == 0) return NBE_OK;
     if (n > 0x7fffffffull) { nbe_set_error("direct sum supports at most 2^31-1 bodies"); return NBE_E_UNSUPPORTED; }
-    const unsigned iblocks = cdiv(nt, 256 * ITILE);
-    // Aim for >= 4 workgroups per CU; split the source range across blockIdx.y when targets alone are too few.
+    const unsigned iblocks = cdiv(nt, BLOCK * ITILE);
+    // Aim for >= 16 waves per CU; split the source range across blockIdx.y when targets alone are too few.
+    const unsigned want_blocks = 4096 * 64 / BLOCK;
     unsigned jsplit = 1;
-    if (iblocks < 1024) jsplit = cdiv(1024, iblocks);
-    const unsigned jtiles = cdiv(n, 256);
+    if (iblocks < want_blocks) jsplit = cdiv(want_blocks, iblocks);
+    const unsigned jtiles = cdiv(n, DIRECT_TILE);
     if (jsplit > jtiles) jsplit = jtiles;
     if (jsplit > 64) jsplit = 64;
-    size_t jchunk = (size_t)cdiv(cdiv(n, jsplit), 256) * 256;
+    size_t jchunk = (size_t)cdiv(cdiv(n, jsplit), DIRECT_TILE) * DIRECT_TILE;
     jsplit = cdiv(n, jchunk);
 
     const double eps = e->cfg.eps;
@@ -150,11 +274,11 @@ static int launch_direct(nbe_engine* e, const void* src, uint64_t t0, uint64_t t
     if (jsplit == 1) {
         dim3 grid(iblocks, 1);
         if (fused)
-            hipLaunchKernelGGL((direct_kernel<R, A, ITILE, OUT_FUSED>), grid, dim3(256), 0, e->stream, (const R4*)src,
+            hipLaunchKernelGGL((DirectKernel<R, A, ITILE, BLOCK, OUT_FUSED>::fn()), grid, dim3(BLOCK), 0, e->stream, (const R4*)src,
                                (int)n, (int)t0, (int)t1, (int)jchunk, floor2, G, dt, acc, pos_in, vel_in, pos_out,
                                vel_out, mirror_out);
         else
-            hipLaunchKernelGGL((direct_kernel<R, A, ITILE, OUT_ACC>), grid, dim3(256), 0, e->stream, (const R4*)src,
+            hipLaunchKernelGGL((DirectKernel<R, A, ITILE, BLOCK, OUT_ACC>::fn()), grid, dim3(BLOCK), 0, e->stream, (const R4*)src,
                                (int)n, (int)t0, (int)t1, (int)jchunk, floor2, G, dt, acc, pos_in, vel_in, pos_out,
                                vel_out, mirror_out);
         NBE_HIP(hipGetLastError());
@@ -169,7 +293,7 @@ static int launch_direct(nbe_engine* e, const void* src, uint64_t t0, uint64_t t
         e->partial_len = need;
     }
     dim3 grid(iblocks, jsplit);
-    hipLaunchKernelGGL((direct_kernel<R, A, ITILE, OUT_PARTIAL>), grid, dim3(256), 0, e->stream, (const R4*)src, (int)n,
+    hipLaunchKernelGGL((DirectKernel<R, A, ITILE, BLOCK, OUT_PARTIAL>::fn()), grid, dim3(BLOCK), 0, e->stream, (const R4*)src, (int)n,
                        (int)t0, (int)t1, (int)jchunk, floor2, G, dt, (A4*)e->partial, pos_in, vel_in, pos_out, vel_out,
                        mirror_out);
     NBE_HIP(hipGetLastError());
@@ -190,9 +314,9 @@ int direct_forces(nbe_engine* e, int src_buf, uint64_t t0, uint64_t t1, bool fus
 {
     e->stats.interactions = (uint64_t)(t1 - t0) * (uint64_t)(e->n ? e->n - 1 : 0);
     switch (e->cfg.precision) {
-    case NBE_PREC_F32: return launch_direct<float, float, 4>(e, e->posm[src_buf], t0, t1, fused, src_buf, dst_buf);
-    case NBE_PREC_MIXED: return launch_direct<float, double, 4>(e, e->mirror[src_buf], t0, t1, fused, src_buf, dst_buf);
-    case NBE_PREC_F64: return launch_direct<double, double, 2>(e, e->posm[src_buf], t0, t1, fused, src_buf, dst_buf);
+    case NBE_PREC_F32: return launch_direct<float, float, 4, 64>(e, e->posm[src_buf], t0, t1, fused, src_buf, dst_buf);
+    case NBE_PREC_MIXED: return launch_direct<float, double, 4, 64>(e, e->mirror[src_buf], t0, t1, fused, src_buf, dst_buf);
+    case NBE_PREC_F64: return launch_direct<double, double, 2, 256>(e, e->posm[src_buf], t0, t1, fused, src_buf, dst_buf);
     }
     nbe_set_error("unknown precision %d", e->cfg.precision);
     return NBE_E_INVALID;

@@ -44,7 +44,8 @@ class EngineError(RuntimeError):
 
 
 def library_path():
-    return os.path.join(_HERE, "libnbody_engine.so")
+    """The in-tree library; NBODY_AMD_LIB overrides it (used to compare builds of the same sources)."""
+    return os.environ.get("NBODY_AMD_LIB") or os.path.join(_HERE, "libnbody_engine.so")
 
 
 _lib = None
