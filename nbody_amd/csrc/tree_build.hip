@@ -156,6 +156,7 @@ __device__ __forceinline__ uint32_t cell_index(double x, double lo, double cell)
 
 // One key per body.  A body is kept iff lo <= p < hi on every axis (contains, tree.go:65-72; NaN fails);
 // others get the all-ones key, sort to the end and stay out of the tree for good (tree.go:290-292).
+// (Counting the live bodies here with one atomic per wave cost 180 us at 1M bodies: 16k atomics on one word.)
 template <typename R4>
 __global__ __launch_bounds__(256) void keys_kernel(const R4* __restrict__ posm, int n, double lox, double loy, double loz,
                                                    double width, uint64_t* __restrict__ keys, uint32_t* __restrict__ idx,
@@ -177,8 +178,15 @@ __global__ __launch_bounds__(256) void keys_kernel(const R4* __restrict__ posm, 
         keys[i] = key;
         idx[i] = (uint32_t)i;
     }
-    unsigned long long b = __ballot(alive);
-    if ((threadIdx.x & 63) == 0 && b) atomicAdd(&counters[0], (int)__popcll(b));
+    (void)alive;
+    (void)counters;   // the number of live bodies falls out of the sort: see set_alive_count_kernel
+}
+
+// After the exclusive scan of the last radix pass (key bits 56..63), the offset of digit 255 in block 0 is the
+// number of keys below 0xff00...: every live key (63 bits) sorts below, the all-ones dead key at or above.
+__global__ void set_alive_count_kernel(const uint32_t* __restrict__ scanned_hist, int nblocks, int* __restrict__ counters)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) counters[0] = (int)scanned_hist[(size_t)255 * nblocks];
 }
 
 // ---- LSD radix sort, 8-bit digits, (key, index) pairs ---------------------------------------------------------
@@ -332,9 +340,15 @@ __global__ __launch_bounds__(256) void mark_cells_kernel(const int* __restrict__
     if (par < 0 || bt_level[par] != lvl) atomicOr(&lvlmask[bt_first[i]], 1u << lvl);
 }
 
-template <typename NodeT> __device__ __forceinline__ void set_edge(NodeT& nd, double w);
-template <> __device__ __forceinline__ void set_edge<NodeF>(NodeF& nd, double w) { nd.w2 = (float)(w * w); }
-template <> __device__ __forceinline__ void set_edge<NodeD>(NodeD& nd, double w) { nd.w = w; }
+// fp32 nodes store (edge / theta)^2 for the walk's one-compare opening test; theta = 0 ("always open") maps to
+// the largest float.  fp64 nodes store the edge itself.
+template <typename NodeT> __device__ __forceinline__ void set_edge(NodeT& nd, double w, double theta);
+template <> __device__ __forceinline__ void set_edge<NodeF>(NodeF& nd, double w, double theta)
+{
+    const double q = theta > 0.0 ? (w / theta) * (w / theta) : (w > 0.0 ? 3.0e38 : 0.0);
+    nd.w2 = (float)fmin(q, 3.0e38);
+}
+template <> __device__ __forceinline__ void set_edge<NodeD>(NodeD& nd, double w, double) { nd.w = w; }
 
 // Writes the pre-order node array: thread t < n handles sorted leaf t, thread n + i handles binary node i.
 // cellcnt[a] = number of branching cells whose first leaf is < a (exclusive scan of popcount(lvlmask)).
@@ -343,7 +357,7 @@ __global__ __launch_bounds__(256) void emit_nodes_kernel(int n, int* __restrict_
                                                          const int* __restrict__ bt_first, const int* __restrict__ bt_last,
                                                          const int* __restrict__ bt_parent, const uint8_t* __restrict__ bt_level,
                                                          const uint32_t* __restrict__ lvlmask, const uint32_t* __restrict__ cellcnt,
-                                                         double bound_width, NodeT* __restrict__ nodes,
+                                                         double bound_width, double theta, NodeT* __restrict__ nodes,
                                                          uint8_t* __restrict__ node_level, double* __restrict__ node_sum)
 {
     const int na = counters[0];
@@ -359,7 +373,7 @@ __global__ __launch_bounds__(256) void emit_nodes_kernel(int n, int* __restrict_
         const R4 p = posm[t];
         NodeT nd;
         nd.x = p.x; nd.y = p.y; nd.z = p.z; nd.m = p.w;
-        set_edge<NodeT>(nd, 0.0);
+        set_edge<NodeT>(nd, 0.0, theta);
         nd.skip = pos + 1;
         nodes[pos] = nd;
         node_level[pos] = 255;
@@ -379,7 +393,7 @@ __global__ __launch_bounds__(256) void emit_nodes_kernel(int n, int* __restrict_
     const int pos = a + (int)cellcnt[a] + __popc(lvlmask[a] & ((1u << lvl) - 1u));
     NodeT nd;
     nd.x = 0; nd.y = 0; nd.z = 0; nd.m = 0;
-    set_edge<NodeT>(nd, bound_width * (1.0 / (double)(1u << lvl)));   // exact: halving a power of two
+    set_edge<NodeT>(nd, bound_width * (1.0 / (double)(1u << lvl)), theta);   // edge: exact halving of a power of two
     nd.skip = (b + 1) + (int)cellcnt[b + 1];
     nodes[pos] = nd;
     node_level[pos] = (uint8_t)lvl;
@@ -449,11 +463,12 @@ int tree_workspace_reserve(nbe_engine* e)
     NBE_HIP(hipMalloc((void**)&w.bt_level, cap));
     NBE_HIP(hipMalloc((void**)&w.lvlmask, (cap + 1) * 4));
     NBE_HIP(hipMalloc((void**)&w.cellcnt, (cap + 1) * 4));
-    NBE_HIP(hipMalloc((void**)&w.nodes, 2 * cap * node_bytes));
+    NBE_HIP(hipMalloc((void**)&w.nodes, (2 * cap + 2) * node_bytes));   // the walk prefetches one record past the end
+    NBE_HIP(hipMemsetAsync(w.nodes, 0, (2 * cap + 2) * node_bytes, e->stream));
     NBE_HIP(hipMalloc((void**)&w.node_level, 2 * cap));
     NBE_HIP(hipMalloc((void**)&w.node_sum, 2 * cap * 4 * sizeof(double)));
     NBE_HIP(hipMalloc((void**)&w.counters, 16 * sizeof(int)));
-    NBE_HIP(hipMalloc((void**)&w.d_interactions, sizeof(unsigned long long)));
+    NBE_HIP(hipMalloc((void**)&w.d_interactions, 8 * sizeof(unsigned long long)));
     NBE_HIP(hipMemsetAsync(w.counters, 0, 16 * sizeof(int), e->stream));
     NBE_HIP(hipMemsetAsync(w.d_interactions, 0, sizeof(unsigned long long), e->stream));
     w.cap = cap;
@@ -487,6 +502,7 @@ static int sort_and_build_t(nbe_engine* e)
         hipLaunchKernelGGL(radix_hist_kernel, dim3(nblocks), dim3(256), 0, e->stream, w.keys[in], n, shift, nblocks,
                            w.block_hist);
         NBE_TRY((device_exclusive_scan<false>(e, w.block_hist, w.block_hist, (size_t)256 * nblocks)));
+        if (pass == 7) hipLaunchKernelGGL(set_alive_count_kernel, dim3(1), dim3(64), 0, e->stream, w.block_hist, nblocks, w.counters);
         hipLaunchKernelGGL(radix_scatter_kernel, dim3(nblocks), dim3(256), 0, e->stream, w.keys[in], w.sidx[in],
                            w.keys[in ^ 1], w.sidx[in ^ 1], w.block_hist, n, shift, nblocks);
         NBE_HIP(hipGetLastError());
@@ -510,7 +526,7 @@ static int sort_and_build_t(nbe_engine* e)
     NBE_HIP(hipGetLastError());
     NBE_TRY((device_exclusive_scan<true>(e, w.lvlmask, w.cellcnt, (size_t)n + 1)));
     hipLaunchKernelGGL((emit_nodes_kernel<R4, NodeT>), dim3(cdiv(2 * (size_t)n, 256)), dim3(256), 0, e->stream, n, w.counters,
-                       sorted_pos, w.bt_first, w.bt_last, w.bt_parent, w.bt_level, w.lvlmask, w.cellcnt, W, (NodeT*)w.nodes,
+                       sorted_pos, w.bt_first, w.bt_last, w.bt_parent, w.bt_level, w.lvlmask, w.cellcnt, W, e->cfg.theta, (NodeT*)w.nodes,
                        w.node_level, w.node_sum);
     NBE_HIP(hipGetLastError());
     for (int level = 21; level >= 0; level--) {
