@@ -64,7 +64,9 @@ struct TreeWork {
     uint32_t* cellcnt = nullptr;    // exclusive scan of popcount(lvlmask), n+1 entries
     void* nodes = nullptr;          // NodeF[2n] or NodeD[2n]
     uint8_t* node_level = nullptr;  // per pre-order node: depth of a branching cell, 255 for a leaf
-    double* node_sum = nullptr;     // per pre-order node: fp64 (mass, m*x, m*y, m*z)
+    double* node_sum = nullptr;     // per pre-order node: fp64 (mass, m*x, m*y, m*z)  (fp64 node records only)
+    double* prefix = nullptr;       // fp32 node records: fp64 prefix sums of (m, m*x, m*y, m*z) over sorted bodies
+    double* prefix_tiles = nullptr;
     int* counters = nullptr;        // device scalars: [0] n_alive, [1] total nodes, [2] branching cells
     unsigned long long* d_interactions = nullptr;
 };

@@ -350,15 +350,123 @@ template <> __device__ __forceinline__ void set_edge<NodeF>(NodeF& nd, double w,
 }
 template <> __device__ __forceinline__ void set_edge<NodeD>(NodeD& nd, double w, double) { nd.w = w; }
 
+// ---- fp64 prefix sums of (m, m*x, m*y, m*z) over the sorted bodies ---------------------------------------------
+// A cell covers a contiguous range [a, b] of sorted bodies, so its mass and first moments are differences of
+// these prefix sums: P[b+1] - P[a].  Used for fp32 node records: the cancellation error of the difference
+// (~1e-16 * |P|) stays below the fp32 rounding of the stored centre of mass.  fp64 node records are reduced
+// level by level instead (cell_mass_kernel) to keep full fp64 accuracy.
+#define PSUM_TILE 2048   // bodies per workgroup (256 threads x 8)
+
+struct D4 { double m, x, y, z; };
+__device__ __forceinline__ D4 d4_add(D4 a, D4 b) { return D4{a.m + b.m, a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ D4 d4_shfl_up(D4 v, int d)
+{
+    return D4{__shfl_up(v.m, d, 64), __shfl_up(v.x, d, 64), __shfl_up(v.y, d, 64), __shfl_up(v.z, d, 64)};
+}
+
+template <typename R4> __device__ __forceinline__ D4 body_moments(const R4* __restrict__ posm, int i, int n)
+{
+    if (i >= n) return D4{0, 0, 0, 0};
+    const R4 p = posm[i];
+    const double m = (double)p.w;
+    return D4{m, m * (double)p.x, m * (double)p.y, m * (double)p.z};
+}
+
+// Exclusive scan across the 256 threads of a workgroup; *total = workgroup sum.
+__device__ __forceinline__ D4 block_excl_scan_d4(D4 v, D4* total)
+{
+    __shared__ D4 wsum[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    D4 inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        D4 t = d4_shfl_up(inc, d);
+        if (lane >= d) inc = d4_add(inc, t);
+    }
+    if (lane == 63) wsum[wave] = inc;
+    // exclusive value = inclusive value of the lane below (never "inclusive - own": that would round twice
+    // and turn a non-finite dead body into NaN for everyone)
+    D4 excl = d4_shfl_up(inc, 1);
+    if (lane == 0) excl = D4{0, 0, 0, 0};
+    __syncthreads();
+    D4 base{0, 0, 0, 0}, tot{0, 0, 0, 0};
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        if (w < wave) base = d4_add(base, wsum[w]);
+        tot = d4_add(tot, wsum[w]);
+    }
+    __syncthreads();
+    *total = tot;
+    return d4_add(base, excl);
+}
+
+template <typename R4>
+__global__ __launch_bounds__(256) void psum_reduce_kernel(const R4* __restrict__ posm, int n, D4* __restrict__ tile_sums)
+{
+    const int base = blockIdx.x * PSUM_TILE + threadIdx.x * 8;
+    D4 s{0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 8; k++) s = d4_add(s, body_moments(posm, base + k, n));
+    D4 tot;
+    block_excl_scan_d4(s, &tot);
+    if (threadIdx.x == 0) tile_sums[blockIdx.x] = tot;
+}
+
+// One workgroup turns the tile sums into exclusive tile offsets, in place.
+__global__ __launch_bounds__(256) void psum_scan_sums_kernel(D4* __restrict__ sums, int nsums)
+{
+    D4 carry{0, 0, 0, 0};
+    for (int base = 0; base < nsums; base += 256 * 4) {
+        D4 v[4], s{0, 0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int i = base + threadIdx.x * 4 + k;
+            v[k] = i < nsums ? sums[i] : D4{0, 0, 0, 0};
+            s = d4_add(s, v[k]);
+        }
+        D4 tot;
+        D4 off = d4_add(carry, block_excl_scan_d4(s, &tot));
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int i = base + threadIdx.x * 4 + k;
+            if (i < nsums) sums[i] = off;
+            off = d4_add(off, v[k]);
+        }
+        carry = d4_add(carry, tot);
+    }
+}
+
+// prefix[i] = sum over bodies k < i, for i in [0, n]; summation order is fixed (thread-serial, then wave, then
+// workgroup, then tile offsets), so every engine computes the same bits.
+template <typename R4>
+__global__ __launch_bounds__(256) void psum_apply_kernel(const R4* __restrict__ posm, int n, const D4* __restrict__ tile_offsets,
+                                                         D4* __restrict__ prefix)
+{
+    const int base = blockIdx.x * PSUM_TILE + threadIdx.x * 8;
+    D4 v[8], s{0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 8; k++) { v[k] = body_moments(posm, base + k, n); s = d4_add(s, v[k]); }
+    D4 tot;
+    D4 off = d4_add(tile_offsets[blockIdx.x], block_excl_scan_d4(s, &tot));
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        if (base + k <= n) prefix[base + k] = off;
+        off = d4_add(off, v[k]);
+    }
+}
+
 // Writes the pre-order node array: thread t < n handles sorted leaf t, thread n + i handles binary node i.
 // cellcnt[a] = number of branching cells whose first leaf is < a (exclusive scan of popcount(lvlmask)).
-template <typename R4, typename NodeT>
+// PREFIX: cells get their mass and centre of mass here, from the prefix sums; otherwise leaves seed node_sum
+// and cell_mass_kernel fills the cells afterwards.
+template <typename R4, typename NodeT, bool PREFIX>
 __global__ __launch_bounds__(256) void emit_nodes_kernel(int n, int* __restrict__ counters, const R4* __restrict__ posm,
                                                          const int* __restrict__ bt_first, const int* __restrict__ bt_last,
                                                          const int* __restrict__ bt_parent, const uint8_t* __restrict__ bt_level,
                                                          const uint32_t* __restrict__ lvlmask, const uint32_t* __restrict__ cellcnt,
                                                          double bound_width, double theta, NodeT* __restrict__ nodes,
-                                                         uint8_t* __restrict__ node_level, double* __restrict__ node_sum)
+                                                         uint8_t* __restrict__ node_level, double* __restrict__ node_sum,
+                                                         const D4* __restrict__ prefix)
 {
     const int na = counters[0];
     const int t = blockIdx.x * 256 + threadIdx.x;
@@ -376,12 +484,14 @@ __global__ __launch_bounds__(256) void emit_nodes_kernel(int n, int* __restrict_
         set_edge<NodeT>(nd, 0.0, theta);
         nd.skip = pos + 1;
         nodes[pos] = nd;
-        node_level[pos] = 255;
-        const double m = (double)p.w;
-        node_sum[4 * (size_t)pos + 0] = m;
-        node_sum[4 * (size_t)pos + 1] = m * (double)p.x;
-        node_sum[4 * (size_t)pos + 2] = m * (double)p.y;
-        node_sum[4 * (size_t)pos + 3] = m * (double)p.z;
+        if (!PREFIX) {
+            node_level[pos] = 255;
+            const double m = (double)p.w;
+            node_sum[4 * (size_t)pos + 0] = m;
+            node_sum[4 * (size_t)pos + 1] = m * (double)p.x;
+            node_sum[4 * (size_t)pos + 2] = m * (double)p.y;
+            node_sum[4 * (size_t)pos + 3] = m * (double)p.z;
+        }
         return;
     }
     const int i = t - n;
@@ -393,10 +503,16 @@ __global__ __launch_bounds__(256) void emit_nodes_kernel(int n, int* __restrict_
     const int pos = a + (int)cellcnt[a] + __popc(lvlmask[a] & ((1u << lvl) - 1u));
     NodeT nd;
     nd.x = 0; nd.y = 0; nd.z = 0; nd.m = 0;
+    if (PREFIX) {
+        const D4 lo = prefix[a], hi = prefix[b + 1];
+        const double m = hi.m - lo.m;
+        const double inv = m != 0.0 ? 1.0 / m : 0.0;
+        nd.x = (hi.x - lo.x) * inv; nd.y = (hi.y - lo.y) * inv; nd.z = (hi.z - lo.z) * inv; nd.m = m;
+    }
     set_edge<NodeT>(nd, bound_width * (1.0 / (double)(1u << lvl)), theta);   // edge: exact halving of a power of two
     nd.skip = (b + 1) + (int)cellcnt[b + 1];
     nodes[pos] = nd;
-    node_level[pos] = (uint8_t)lvl;
+    if (!PREFIX) node_level[pos] = (uint8_t)lvl;
 }
 
 // One depth per launch, deepest first: a cell sums its children (already final) in pre-order, which is the
@@ -443,7 +559,7 @@ int tree_workspace_reserve(nbe_engine* e)
     void** ptrs[] = {(void**)&w.keys[0], (void**)&w.keys[1], (void**)&w.sidx[0], (void**)&w.sidx[1], (void**)&w.block_hist,
                      (void**)&w.scan_tmp, (void**)&w.bt_first, (void**)&w.bt_last, (void**)&w.bt_parent, (void**)&w.bt_level,
                      (void**)&w.lvlmask, (void**)&w.cellcnt, (void**)&w.nodes, (void**)&w.node_level, (void**)&w.node_sum,
-                     (void**)&w.counters, (void**)&w.d_interactions};
+                     (void**)&w.counters, (void**)&w.d_interactions, (void**)&w.prefix, (void**)&w.prefix_tiles};
     for (void** p : ptrs) NBE_TRY(free_ptr(p));
     const size_t cap = n > 0 ? n : 1;
     const size_t nblocks = cdiv(cap, SORT_TILE);
@@ -465,8 +581,13 @@ int tree_workspace_reserve(nbe_engine* e)
     NBE_HIP(hipMalloc((void**)&w.cellcnt, (cap + 1) * 4));
     NBE_HIP(hipMalloc((void**)&w.nodes, (2 * cap + 2) * node_bytes));   // the walk prefetches one record past the end
     NBE_HIP(hipMemsetAsync(w.nodes, 0, (2 * cap + 2) * node_bytes, e->stream));
-    NBE_HIP(hipMalloc((void**)&w.node_level, 2 * cap));
-    NBE_HIP(hipMalloc((void**)&w.node_sum, 2 * cap * 4 * sizeof(double)));
+    if (e->force64) {
+        NBE_HIP(hipMalloc((void**)&w.node_level, 2 * cap));
+        NBE_HIP(hipMalloc((void**)&w.node_sum, 2 * cap * 4 * sizeof(double)));
+    } else {
+        NBE_HIP(hipMalloc((void**)&w.prefix, (cap + 1) * 4 * sizeof(double)));
+        NBE_HIP(hipMalloc((void**)&w.prefix_tiles, ((size_t)cdiv(cap + 1, PSUM_TILE) + 1) * 4 * sizeof(double)));
+    }
     NBE_HIP(hipMalloc((void**)&w.counters, 16 * sizeof(int)));
     NBE_HIP(hipMalloc((void**)&w.d_interactions, 8 * sizeof(unsigned long long)));
     NBE_HIP(hipMemsetAsync(w.counters, 0, 16 * sizeof(int), e->stream));
@@ -525,15 +646,26 @@ static int sort_and_build_t(nbe_engine* e)
                        w.lvlmask);
     NBE_HIP(hipGetLastError());
     NBE_TRY((device_exclusive_scan<true>(e, w.lvlmask, w.cellcnt, (size_t)n + 1)));
-    hipLaunchKernelGGL((emit_nodes_kernel<R4, NodeT>), dim3(cdiv(2 * (size_t)n, 256)), dim3(256), 0, e->stream, n, w.counters,
-                       sorted_pos, w.bt_first, w.bt_last, w.bt_parent, w.bt_level, w.lvlmask, w.cellcnt, W, e->cfg.theta, (NodeT*)w.nodes,
-                       w.node_level, w.node_sum);
-    NBE_HIP(hipGetLastError());
-    for (int level = 21; level >= 0; level--) {
-        hipLaunchKernelGGL((cell_mass_kernel<NodeT>), dim3(cdiv(2 * (size_t)n, 256)), dim3(256), 0, e->stream, w.counters,
-                           level, (NodeT*)w.nodes, w.node_level, w.node_sum);
+    constexpr bool PREFIX = !__is_same(NodeT, NodeD);
+    if (PREFIX) {
+        const unsigned tiles = cdiv((size_t)n + 1, PSUM_TILE);
+        hipLaunchKernelGGL((psum_reduce_kernel<R4>), dim3(tiles), dim3(256), 0, e->stream, sorted_pos, n, (D4*)w.prefix_tiles);
+        hipLaunchKernelGGL(psum_scan_sums_kernel, dim3(1), dim3(256), 0, e->stream, (D4*)w.prefix_tiles, (int)tiles);
+        hipLaunchKernelGGL((psum_apply_kernel<R4>), dim3(tiles), dim3(256), 0, e->stream, sorted_pos, n,
+                           (const D4*)w.prefix_tiles, (D4*)w.prefix);
+        NBE_HIP(hipGetLastError());
     }
+    hipLaunchKernelGGL((emit_nodes_kernel<R4, NodeT, PREFIX>), dim3(cdiv(2 * (size_t)n, 256)), dim3(256), 0, e->stream, n,
+                       w.counters, sorted_pos, w.bt_first, w.bt_last, w.bt_parent, w.bt_level, w.lvlmask, w.cellcnt, W,
+                       e->cfg.theta, (NodeT*)w.nodes, w.node_level, w.node_sum, (const D4*)w.prefix);
     NBE_HIP(hipGetLastError());
+    if (!PREFIX) {
+        for (int level = 21; level >= 0; level--) {
+            hipLaunchKernelGGL((cell_mass_kernel<NodeT>), dim3(cdiv(2 * (size_t)n, 256)), dim3(256), 0, e->stream, w.counters,
+                               level, (NodeT*)w.nodes, w.node_level, w.node_sum);
+        }
+        NBE_HIP(hipGetLastError());
+    }
     if (e->timing) NBE_HIP(hipEventRecord(e->ev[2], e->stream));
     return NBE_OK;
 }
