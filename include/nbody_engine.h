@@ -133,6 +133,21 @@ int nbe_device_state(nbe_engine *e, nbe_device_state_t *out);
  * stream.  The previous stream is drained first. */
 int nbe_set_stream(nbe_engine *e, void *hip_stream);
 
+/* ---- frame streaming ----
+ * The reference hands a copy of the live bodies to its output workers before every step through a channel of
+ * capacity 32 (main.go:50-61, 90-101).  Here the copy leaves the GPU on a side stream into a ring of pinned host
+ * buffers while the next step computes, and a library thread delivers it:
+ *   cb(user, frame, n_alive, xyzm, ids)   xyzm = n_alive x (x, y, z, mass) as fp32 (the record the reference's own
+ *                                         frame store keeps, gob.go:54-61, minus the constant radius), ids = body IDs;
+ *                                         both valid only during the call; bodies come in device order.
+ * `every` = steps between frames (the reference's iterPerFrame, main.go:29); frame k is the state before step
+ * k*every since the call, numbered from `first_frame` (startFrame, main.go:41-47).  `slots` buffers are in flight at
+ * most (the channel capacity); nbe_step blocks when all are waiting for the callback, as the channel send would.
+ * nbe_frame_stream_end delivers what is pending and stops the thread; nbe_destroy and nbe_upload imply it. */
+typedef void (*nbe_frame_cb)(void *user, int frame, size_t n_alive, const float *xyzm, const uint64_t *ids);
+int nbe_frame_stream_begin(nbe_engine *e, int every, int slots, int first_frame, nbe_frame_cb cb, void *user);
+int nbe_frame_stream_end(nbe_engine *e);
+
 /* ---- tree inspection (tests) ----
  * Builds the tree of the current state if needed and copies its nodes to the host in depth-first pre-order
  * (children in octant order 0..7, the order of tree.go:221-225): 6 doubles per node = centre of mass x,y,z,

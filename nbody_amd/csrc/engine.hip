@@ -91,6 +91,7 @@ extern "C" void nbe_destroy(nbe_engine* e)
 {
     if (!e) return;
     (void)hipSetDevice(e->cfg.device);
+    (void)frame_stream_stop(e);
     (void)hipStreamSynchronize(e->stream);
     (void)free_state(e);
     TreeWork& w = e->tw;
@@ -120,6 +121,7 @@ extern "C" int nbe_upload(nbe_engine* e, size_t n, const double* pos, const doub
     if (n > 0 && (!pos || !vel || !mass)) { nbe_set_error("nbe_upload: NULL array"); return NBE_E_INVALID; }
     if (n > 0x7fffffffull) { nbe_set_error("at most 2^31-1 bodies"); return NBE_E_UNSUPPORTED; }
     NBE_TRY(use_device(e));
+    NBE_TRY(frame_stream_stop(e));
     NBE_HIP(hipStreamSynchronize(e->stream));
     NBE_TRY(free_state(e));
     e->n = n;
@@ -235,6 +237,7 @@ extern "C" int nbe_download(nbe_engine* e, double* pos, double* vel, double* mas
 
 static int force_pass(nbe_engine* e, uint64_t t0, uint64_t t1, bool fused, bool count = false)
 {
+    if (fused) NBE_TRY(frame_stream_guard_write(e, e->cur ^ 1));
     if (e->cfg.mode == NBE_MODE_TREE) return tree_forces(e, e->cur, t0, t1, fused, count, e->cur ^ 1);
     return direct_forces(e, e->cur, t0, t1, fused, e->cur ^ 1);
 }
@@ -244,6 +247,7 @@ extern "C" int nbe_shard_prepare(nbe_engine* e)
     if (!e) { nbe_set_error("engine is NULL"); return NBE_E_INVALID; }
     NBE_TRY(use_device(e));
     if (e->advance_pending) { nbe_set_error("nbe_shard_prepare before nbe_shard_commit"); return NBE_E_INVALID; }
+    if (!e->prepared) NBE_TRY(frame_stream_before_step(e));
     if (e->cfg.mode == NBE_MODE_TREE && !e->prepared) NBE_TRY(tree_sort_and_build(e));
     e->prepared = true;
     return NBE_OK;
@@ -321,6 +325,7 @@ extern "C" int nbe_device_state(nbe_engine* e, nbe_device_state_t* out)
 
 static int step_once_full(nbe_engine* e)
 {
+    NBE_TRY(frame_stream_before_step(e));
     if (e->cfg.mode == NBE_MODE_TREE && !e->prepared) NBE_TRY(tree_sort_and_build(e));
     else if (e->timing) {
         NBE_HIP(hipEventRecord(e->ev[0], e->stream));

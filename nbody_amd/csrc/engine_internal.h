@@ -4,6 +4,11 @@
 #include <cstdint>
 #include <cstdio>
 #include <string>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include <thread>
+#include <vector>
 #include "nbody_engine.h"
 
 // ---- error plumbing -------------------------------------------------------------------------------
@@ -71,6 +76,37 @@ struct TreeWork {
     unsigned long long* d_interactions = nullptr;
 };
 
+// Ring of pinned host buffers that carries frames from the GPU to a delivery thread.
+struct FrameSlot {
+    float* xyzm = nullptr;        // pinned, n x 4 floats
+    uint32_t* orig = nullptr;     // pinned, n x u32 (device order -> upload index)
+    int* n_alive = nullptr;       // pinned scalar
+    int* d_n_alive = nullptr;     // device snapshot of the live count, taken on the compute stream
+    hipEvent_t done = nullptr;    // copy finished (side stream)
+    int frame = 0;
+    bool busy = false;
+};
+
+struct FrameStream {
+    bool active = false;
+    int every = 1, first_frame = 0;
+    uint64_t step_base = 0;       // stats.steps when streaming began
+    nbe_frame_cb cb = nullptr;
+    void* user = nullptr;
+    hipStream_t side = nullptr;
+    hipEvent_t state_ready = nullptr;
+    hipEvent_t copy_done[2] = {nullptr, nullptr};   // per state buffer: the last copy that read it has finished
+    bool copy_pending[2] = {false, false};
+    float4* staging = nullptr;    // device: fp32 copy of an fp64 state
+    std::vector<FrameSlot> slots;
+    std::deque<int> queue;        // slots waiting for delivery, in frame order
+    std::mutex mu;
+    std::condition_variable cv_work, cv_free;
+    std::thread worker;
+    bool stop = false;
+    std::vector<uint64_t> ids_scratch;
+};
+
 struct nbe_engine {
     nbe_config cfg{};
     size_t n = 0;
@@ -100,6 +136,7 @@ struct nbe_engine {
     nbe_stats_t stats{};
     size_t host_nalive = 0;
     double* d_energy = nullptr;     // device scratch for nbe_energy
+    FrameStream fs;
 };
 
 // ---- functions implemented across the translation units ----------------------------------------------
@@ -112,5 +149,9 @@ int tree_sort_and_build(nbe_engine* e);         // sorts cur -> cur^1, flips e->
 int tree_forces(nbe_engine* e, int src_buf, uint64_t t0, uint64_t t1, bool fused, bool count, int dst_buf);
 // energy.hip
 int energy_compute(nbe_engine* e, double* ke, double* pe, double mom[3]);
+// frames.hip
+int frame_stream_before_step(nbe_engine* e);    // called at the top of every step
+int frame_stream_guard_write(nbe_engine* e, int buf);
+int frame_stream_stop(nbe_engine* e);
 
 static inline unsigned cdiv(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }

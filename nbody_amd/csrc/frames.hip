@@ -1,0 +1,168 @@
+// Frame streaming: the copy of live bodies that the reference sends to its output workers before every step
+// (main.go:90-101, channel of capacity 32 at main.go:50) leaves the GPU on a side stream into pinned host
+// buffers while the step computes, and a delivery thread calls the host's callback.
+#include "engine_internal.h"
+
+__global__ __launch_bounds__(256) void narrow_state_kernel(const double4* __restrict__ posm, float4* __restrict__ out, int n)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const double4 p = posm[i];
+    out[i] = make_float4((float)p.x, (float)p.y, (float)p.z, (float)p.w);
+}
+
+static void delivery_loop(nbe_engine* e)
+{
+    FrameStream& fs = e->fs;
+    (void)hipSetDevice(e->cfg.device);
+    for (;;) {
+        int slot;
+        {
+            std::unique_lock<std::mutex> lk(fs.mu);
+            fs.cv_work.wait(lk, [&] { return fs.stop || !fs.queue.empty(); });
+            if (fs.queue.empty()) return;            // stop requested and nothing left to deliver
+            slot = fs.queue.front();
+            fs.queue.pop_front();
+        }
+        FrameSlot& s = fs.slots[slot];
+        (void)hipEventSynchronize(s.done);
+        const int na_raw = *s.n_alive;               // -1: no tree build has removed anything yet
+        size_t na = na_raw < 0 ? e->n : (size_t)na_raw;
+        if (na > e->n) na = e->n;
+        fs.ids_scratch.resize(na);
+        for (size_t d = 0; d < na; d++) fs.ids_scratch[d] = e->ids[s.orig[d]];
+        fs.cb(fs.user, s.frame, na, s.xyzm, fs.ids_scratch.data());
+        {
+            std::lock_guard<std::mutex> lk(fs.mu);
+            s.busy = false;
+        }
+        fs.cv_free.notify_all();
+    }
+}
+
+extern "C" int nbe_frame_stream_begin(nbe_engine* e, int every, int slots, int first_frame, nbe_frame_cb cb, void* user)
+{
+    if (!e || !cb) { nbe_set_error("nbe_frame_stream_begin: NULL argument"); return NBE_E_INVALID; }
+    if (every < 1 || slots < 1 || slots > 1024) { nbe_set_error("every must be >= 1 and slots in 1..1024"); return NBE_E_INVALID; }
+    if (e->fs.active) { nbe_set_error("frame streaming is already on"); return NBE_E_INVALID; }
+    NBE_HIP(hipSetDevice(e->cfg.device));
+    FrameStream& fs = e->fs;
+    const size_t cap = e->n > 0 ? e->n : 1;
+    fs.every = every; fs.first_frame = first_frame; fs.cb = cb; fs.user = user;
+    fs.step_base = e->stats.steps;
+    fs.stop = false; fs.copy_pending[0] = fs.copy_pending[1] = false;
+    fs.queue.clear();
+    NBE_HIP(hipStreamCreateWithFlags(&fs.side, hipStreamNonBlocking));
+    NBE_HIP(hipEventCreateWithFlags(&fs.state_ready, hipEventDisableTiming));
+    NBE_HIP(hipEventCreateWithFlags(&fs.copy_done[0], hipEventDisableTiming));
+    NBE_HIP(hipEventCreateWithFlags(&fs.copy_done[1], hipEventDisableTiming));
+    if (e->state64) NBE_HIP(hipMalloc((void**)&fs.staging, cap * sizeof(float4)));
+    fs.slots.assign((size_t)slots, FrameSlot());
+    for (FrameSlot& s : fs.slots) {
+        NBE_HIP(hipHostMalloc((void**)&s.xyzm, cap * 4 * sizeof(float), hipHostMallocDefault));
+        NBE_HIP(hipHostMalloc((void**)&s.orig, cap * sizeof(uint32_t), hipHostMallocDefault));
+        NBE_HIP(hipHostMalloc((void**)&s.n_alive, sizeof(int), hipHostMallocDefault));
+        NBE_HIP(hipMalloc((void**)&s.d_n_alive, sizeof(int)));
+        NBE_HIP(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+    }
+    fs.active = true;
+    fs.worker = std::thread(delivery_loop, e);
+    return NBE_OK;
+}
+
+// Called before any kernel that writes state buffer `buf`: if a frame copy is still reading that buffer, the
+// compute stream waits for it.  (Direct mode writes the other buffer during the overlapping step, so the copy
+// hides behind the whole force pass; tree mode writes the copied buffer again in its force pass, so the copy
+// hides behind the sort and build.)
+int frame_stream_guard_write(nbe_engine* e, int buf)
+{
+    FrameStream& fs = e->fs;
+    if (fs.active && fs.copy_pending[buf]) {
+        NBE_HIP(hipStreamWaitEvent(e->stream, fs.copy_done[buf], 0));
+        fs.copy_pending[buf] = false;
+    }
+    return NBE_OK;
+}
+
+// Called at the top of every step with the state that the step is about to read in e->posm[e->cur].
+int frame_stream_before_step(nbe_engine* e)
+{
+    FrameStream& fs = e->fs;
+    if (!fs.active) return NBE_OK;
+    const uint64_t k = e->stats.steps - fs.step_base;
+    if (k % (uint64_t)fs.every != 0 || e->n == 0) return NBE_OK;
+    int slot = -1;
+    {
+        std::unique_lock<std::mutex> lk(fs.mu);      // back-pressure: wait for a free buffer like a full channel
+        fs.cv_free.wait(lk, [&] {
+            for (size_t i = 0; i < fs.slots.size(); i++)
+                if (!fs.slots[i].busy) { slot = (int)i; return true; }
+            return false;
+        });
+        fs.slots[slot].busy = true;
+    }
+    FrameSlot& s = fs.slots[slot];
+    s.frame = fs.first_frame + (int)(k / (uint64_t)fs.every);
+    const size_t n = e->n;
+    // the build of the coming step resets the live count on the compute stream: snapshot it there first
+    if (e->have_counts)
+        NBE_HIP(hipMemcpyAsync(s.d_n_alive, e->tw.counters, sizeof(int), hipMemcpyDeviceToDevice, e->stream));
+    NBE_HIP(hipEventRecord(fs.state_ready, e->stream));
+    NBE_HIP(hipStreamWaitEvent(fs.side, fs.state_ready, 0));
+    const void* src = e->posm[e->cur];
+    if (e->state64) {
+        hipLaunchKernelGGL(narrow_state_kernel, dim3(cdiv(n, 256)), dim3(256), 0, fs.side, (const double4*)e->posm[e->cur],
+                           fs.staging, (int)n);
+        NBE_HIP(hipGetLastError());
+        src = fs.staging;
+    }
+    NBE_HIP(hipMemcpyAsync(s.xyzm, src, n * sizeof(float4), hipMemcpyDeviceToHost, fs.side));
+    NBE_HIP(hipMemcpyAsync(s.orig, e->orig[e->orig_cur], n * sizeof(uint32_t), hipMemcpyDeviceToHost, fs.side));
+    if (e->have_counts) NBE_HIP(hipMemcpyAsync(s.n_alive, s.d_n_alive, sizeof(int), hipMemcpyDeviceToHost, fs.side));
+    else *s.n_alive = -1;
+    NBE_HIP(hipEventRecord(s.done, fs.side));
+    NBE_HIP(hipEventRecord(fs.copy_done[e->cur], fs.side));
+    fs.copy_pending[e->cur] = true;
+    {
+        std::lock_guard<std::mutex> lk(fs.mu);
+        fs.queue.push_back(slot);
+    }
+    fs.cv_work.notify_one();
+    return NBE_OK;
+}
+
+int frame_stream_stop(nbe_engine* e)
+{
+    FrameStream& fs = e->fs;
+    if (!fs.active) return NBE_OK;
+    {
+        std::lock_guard<std::mutex> lk(fs.mu);
+        fs.stop = true;
+    }
+    fs.cv_work.notify_all();
+    if (fs.worker.joinable()) fs.worker.join();      // delivers everything still queued first
+    (void)hipSetDevice(e->cfg.device);
+    (void)hipStreamSynchronize(fs.side);
+    for (FrameSlot& s : fs.slots) {
+        if (s.xyzm) (void)hipHostFree(s.xyzm);
+        if (s.orig) (void)hipHostFree(s.orig);
+        if (s.n_alive) (void)hipHostFree(s.n_alive);
+        if (s.d_n_alive) (void)hipFree(s.d_n_alive);
+        if (s.done) (void)hipEventDestroy(s.done);
+    }
+    fs.slots.clear();
+    if (fs.staging) { (void)hipFree(fs.staging); fs.staging = nullptr; }
+    if (fs.state_ready) { (void)hipEventDestroy(fs.state_ready); fs.state_ready = nullptr; }
+    for (int b = 0; b < 2; b++)
+        if (fs.copy_done[b]) { (void)hipEventDestroy(fs.copy_done[b]); fs.copy_done[b] = nullptr; }
+    if (fs.side) { (void)hipStreamDestroy(fs.side); fs.side = nullptr; }
+    fs.copy_pending[0] = fs.copy_pending[1] = false;
+    fs.active = false;
+    return NBE_OK;
+}
+
+extern "C" int nbe_frame_stream_end(nbe_engine* e)
+{
+    if (!e) { nbe_set_error("engine is NULL"); return NBE_E_INVALID; }
+    return frame_stream_stop(e);
+}

@@ -629,6 +629,7 @@ static int sort_and_build_t(nbe_engine* e)
         NBE_HIP(hipGetLastError());
         in ^= 1;
     }
+    NBE_TRY(frame_stream_guard_write(e, nxt));
     hipLaunchKernelGGL((permute_kernel<S4>), dim3(nb), dim3(256), 0, e->stream, w.sidx[0], n, (const S4*)e->posm[cur],
                        (const S4*)e->vel[cur], e->orig[e->orig_cur], mixed ? e->mirror[cur] : (const float4*)nullptr,
                        (S4*)e->posm[nxt], (S4*)e->vel[nxt], e->orig[e->orig_cur ^ 1], mixed ? e->mirror[nxt] : (float4*)nullptr);

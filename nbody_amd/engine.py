@@ -19,7 +19,9 @@ _PRECS = {"f32": PREC_F32, "mixed": PREC_MIXED, "f64": PREC_F64}
 EXPORTS = ("nbe_default_config", "nbe_create", "nbe_destroy", "nbe_last_error", "nbe_upload", "nbe_download",
            "nbe_accel", "nbe_step", "nbe_step_timed", "nbe_sync", "nbe_stats", "nbe_energy", "nbe_set_shard",
            "nbe_shard_prepare", "nbe_shard_advance", "nbe_shard_commit", "nbe_device_state", "nbe_set_stream",
-           "nbe_time_force_kernel", "nbe_tree_nodes")
+           "nbe_time_force_kernel", "nbe_tree_nodes", "nbe_frame_stream_begin", "nbe_frame_stream_end")
+
+FRAME_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_size_t, C.POINTER(C.c_float), C.POINTER(C.c_uint64))
 
 
 class Config(C.Structure):
@@ -85,6 +87,8 @@ def load_library():
     lib.nbe_set_stream.argtypes = [vp, vp]
     lib.nbe_time_force_kernel.argtypes = [vp, C.c_int, C.POINTER(C.c_float)]
     lib.nbe_tree_nodes.argtypes = [vp, dp, C.c_size_t, C.POINTER(C.c_size_t)]
+    lib.nbe_frame_stream_begin.argtypes = [vp, C.c_int, C.c_int, C.c_int, FRAME_CB, vp]
+    lib.nbe_frame_stream_end.argtypes = [vp]
     for name in EXPORTS:
         if name not in ("nbe_destroy", "nbe_last_error"):
             getattr(lib, name).restype = C.c_int
@@ -216,6 +220,21 @@ class Engine:
         if cnt.value:
             self._check(self._lib.nbe_tree_nodes(self._h, _dp(out), cnt.value, C.byref(cnt)))
         return out
+
+    # ---- frame streaming ----
+    def frame_stream_begin(self, callback, every=1, slots=32, first_frame=0):
+        """callback(frame, xyzm[n_alive,4] float32, ids[n_alive] uint64) runs on a library thread for the state
+        before every `every`-th step; the arrays are copies the callback may keep."""
+        def tramp(_user, frame, n, xyzm, ids):
+            a = np.ctypeslib.as_array(xyzm, shape=(n, 4)).copy() if n else np.zeros((0, 4), np.float32)
+            i = np.ctypeslib.as_array(ids, shape=(n,)).copy() if n else np.zeros(0, np.uint64)
+            callback(frame, a, i)
+        self._frame_cb = FRAME_CB(tramp)          # keep the thunk alive while streaming
+        self._check(self._lib.nbe_frame_stream_begin(self._h, int(every), int(slots), int(first_frame), self._frame_cb, None))
+
+    def frame_stream_end(self):
+        self._check(self._lib.nbe_frame_stream_end(self._h))
+        self._frame_cb = None
 
     # ---- sharded stepping ----
     def set_shard(self, first, count):

@@ -101,3 +101,34 @@ def test_two_ranks_on_one_gpu_match_single_engine(gpu, tmp_path, mode, precision
     else:
         assert np.abs(res[0]["pos"] - p).max() <= 1e-6 * np.abs(p).max()
         assert np.abs(res[0]["vel"] - v).max() <= 1e-5 * np.abs(v).max()
+
+
+@pytest.mark.parametrize("mode,precision", [("direct", "f32"), ("tree", "f32"), ("tree", "mixed"), ("direct", "f64")])
+def test_frame_stream_delivers_the_state_before_each_step(gpu, mode, precision):
+    """main.go:90-101: a copy of the live bodies goes to the output workers before every iteration.  The streamed
+    frames (side stream + pinned ring + delivery thread) must equal what a synchronous download would have
+    returned at the same point, and arrive in order, also when only a few ring slots exist."""
+    b = physics.makebodies(3000, seed=4)
+    nsteps, every = 12, 3
+    want = {}
+    with Engine(mode=mode, precision=precision, theta=0.7) as e:
+        e.upload(b.pos, b.vel, b.mass, b.ids + 100)
+        for s in range(nsteps):
+            if s % every == 0:
+                p, v, m, ids = e.download()
+                want[7 + s // every] = (p, m, ids)
+            e.step(1)
+    got = []
+    with Engine(mode=mode, precision=precision, theta=0.7) as e:
+        e.upload(b.pos, b.vel, b.mass, b.ids + 100)
+        e.frame_stream_begin(lambda f, xyzm, ids: got.append((f, xyzm, ids)), every=every, slots=2, first_frame=7)
+        e.step(nsteps)
+        e.frame_stream_end()
+        e.step(2)                      # streaming is off again
+    assert [f for f, _, _ in got] == sorted(want)
+    for f, xyzm, ids in got:
+        p, m, want_ids = want[f]
+        order = np.argsort(ids)
+        assert np.array_equal(ids[order], want_ids)
+        assert np.array_equal(xyzm[order, :3], p.astype(np.float32))
+        assert np.array_equal(xyzm[order, 3], m.astype(np.float32))

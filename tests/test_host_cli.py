@@ -1,0 +1,69 @@
+"""The C++ host (host/nbody_main.cpp): the reference's driver loop (main.go) above the C ABI."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "host", "nbody")
+
+
+def run(args, cwd):
+    return subprocess.run([BIN] + args, cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+
+
+def read_frame(path):
+    raw = open(path, "rb").read()
+    n = struct.unpack_from("<I", raw, 0)[0]
+    rec = np.frombuffer(raw, dtype=np.dtype([("id", "<u4"), ("xyzmr", "<f4", 5)]), count=n, offset=4)
+    assert len(raw) == 4 + 24 * n
+    return rec
+
+
+def test_host_builds_and_insists_on_nocollision(tmp_path):
+    assert os.path.exists(BIN), "build it with `make -C host` (or __graft_entry__.build())"
+    r = run(["-n", "10", "-y", "0.001"], tmp_path)
+    assert r.returncode == 2 and b"-nocollision" in r.stdout
+    r = run(["-bogus"], tmp_path)
+    assert r.returncode == 2 and b"flag provided but not defined" in r.stdout
+
+
+def test_host_fails_loudly_without_a_gpu(tmp_path):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    r = run(["-n", "10", "-y", "0.001", "-nocollision", "-norender"], tmp_path)
+    assert r.returncode == 2 and b"no HIP device" in r.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tree", [False, True])
+def test_host_frame_loop_save_and_resume(gpu, tmp_path, tree):
+    """frames = int(y*365*24) and the loop runs frames+1 iterations (main.go:30,80); every iteration sends the
+    state BEFORE its step to the workers (main.go:90-101); -save / -state continue the frame numbering
+    (main.go:42-47, 199-201)."""
+    mode = ["-tree"] if tree else []
+    r = run(["-n", "500", "-y", "0.004", "-nocollision", "-save", "-seed", "5"] + mode, tmp_path)   # frames = 35
+    assert r.returncode == 0, r.stdout.decode()
+    out = r.stdout.decode()
+    assert "bodies: 502" in out and "frames: 35" in out and ("tree: true" if tree else "tree: false") in out
+    files = sorted(os.listdir(tmp_path / "frames"))
+    assert files == [f"{k:010d}.frame" for k in range(36)]
+    f0, f35 = read_frame(tmp_path / "frames" / files[0]), read_frame(tmp_path / "frames" / files[35])
+    assert len(f0) == 502 and set(f0["id"]) == set(range(502))
+    ids = np.argsort(f0["id"])
+    assert list(f0["xyzmr"][ids][0][:4]) == [-9000.0, -100.0, -2000.0, 1e10] and f0["xyzmr"][ids][0][4] == 1.0
+    assert np.isfinite(f35["xyzmr"]).all() and not np.array_equal(np.sort(f0["xyzmr"][:, 0]), np.sort(f35["xyzmr"][:, 0]))
+    state = tmp_path / f"{36:010d}.data"
+    assert state.exists()
+    # resume: 0.001 y = 8 more frames, numbered from 36
+    r = run(["-n", "500", "-y", "0.001", "-nocollision", "-state", str(state), "-frames-dir", "more"] + mode, tmp_path)
+    assert r.returncode == 0, r.stdout.decode()
+    assert sorted(os.listdir(tmp_path / "more")) == [f"{k:010d}.frame" for k in range(36, 36 + 9)]
+    first = read_frame(tmp_path / "more" / f"{36:010d}.frame")
+    assert len(first) >= 495
+    # -norender runs the same loop without frames
+    r = run(["-n", "500", "-y", "0.002", "-nocollision", "-norender"] + mode, tmp_path)
+    assert r.returncode == 0 and b"Done. Took" in r.stdout
