@@ -100,6 +100,11 @@ def cpu_baseline_tree(n, theta):
 
 def main():
     args = parse()
+    # Libraries (RCCL prints a version banner) write to file descriptor 1; keep the real stdout for the one JSON
+    # line and send everything else to stderr.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
     from nbody_amd import Engine, physics
@@ -113,7 +118,10 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
     torch.cuda.set_device(local)
-    if world > 1:
+    force_dist = os.environ.get("NBODY_BENCH_FORCE_DIST") == "1"   # rehearse the RCCL path with a single rank
+    if world > 1 or force_dist:
+        if force_dist and "MASTER_ADDR" not in os.environ:
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     def sync():
@@ -128,8 +136,8 @@ def main():
         eng = Engine(mode=mode, precision=precision, theta=theta, device=local)
         eng.upload(b.pos, b.vel, b.mass)
         del b
-        if world > 1:
-            stepper = ShardedStepper(EngineShard(eng, device_index=local))
+        if world > 1 or force_dist:
+            stepper = ShardedStepper(EngineShard(eng, device_index=local), always_gather=force_dist)
             step_fn = stepper.step
         else:
             eng.set_stream(torch.cuda.current_stream().cuda_stream)
@@ -222,8 +230,8 @@ def main():
                "config": {"workload": workload, "bodies": n, "ic": "Plummer sphere a=2e3 m, M=1e9 kg, seed 1",
                           "dt": 3600.0, "eps": 0.0, "parallelism": f"targets sharded over {world} GPU(s), all-gather of pos+vel per step" if world > 1 else "single GPU"},
                "roofline": roofline, "cpu_baseline": cpu, "extra": extra}
-        print(json.dumps(out), flush=True)
-    if world > 1:
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    if world > 1 or force_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -75,7 +75,9 @@ class EngineShard:
 class ShardedStepper:
     """Drives one rank's shard.  `shard` is an EngineShard (or anything with the same methods)."""
 
-    def __init__(self, shard, rank=None, world=None, group=None):
+    def __init__(self, shard, rank=None, world=None, group=None, always_gather=False):
+        """always_gather: run the collectives even with a single rank (exercises the RCCL path on one GPU)."""
+        self.always_gather = always_gather
         self.shard = shard
         self.group = group
         self.rank = dist.get_rank(group) if rank is None else rank
@@ -84,12 +86,12 @@ class ShardedStepper:
         self.first, self.count, self.per = shard_range(self.n, self.rank, self.world)
         shard.set_shard(self.first, self.count)
         self.even = self.per * self.world == self.n
-        self.backend = dist.get_backend(group) if self.world > 1 else None
+        self.backend = dist.get_backend(group) if (self.world > 1 or always_gather) else None
         self._pad = {}
 
     def _gather(self, full):
         """All-gather the ranks' row ranges of `full` (n x 4) in place."""
-        if self.world == 1:
+        if self.world == 1 and not self.always_gather:
             return
         host_stage = self.backend == "gloo" and full.is_cuda
         work = full.cpu() if host_stage else full
