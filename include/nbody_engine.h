@@ -108,9 +108,10 @@ int nbe_step_timed(nbe_engine *e, nbe_stats_t *stats);
 int nbe_sync(nbe_engine *e);
 int nbe_stats(nbe_engine *e, nbe_stats_t *stats);
 
-/* Total kinetic energy, potential energy (fp64 pair sum, softened by eps) and linear momentum of the
- * live bodies; used for drift checks.  No counterpart in the reference (its only validation is the
- * rendered frames). */
+/* Total kinetic energy, potential energy (softened by eps) and linear momentum of the live bodies; used for
+ * drift checks.  Up to 262,144 bodies the potential is the exact fp64 pair sum; above that, tree mode sums it over
+ * the nodes its walk accepts (same theta as the forces) and direct mode accepts up to 4,194,304 bodies.
+ * No counterpart in the reference (its only validation is the rendered frames). */
 int nbe_energy(nbe_engine *e, double *kinetic, double *potential, double momentum[3]);
 
 /* ---- sharded stepping (one engine per GPU, every engine holds all n bodies as sources) ----

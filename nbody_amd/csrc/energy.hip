@@ -68,8 +68,24 @@ __global__ __launch_bounds__(256) void potential_kernel(const S4* __restrict__ p
     if (threadIdx.x == 0) atomicAdd(&out[4], v);
 }
 
+// out[4] += sum_i m_i * phi_i with phi_i taken from the w component of the acceleration records that an
+// instrumented tree walk left in e->acc (device order).
 template <typename S4>
-static int energy_t(nbe_engine* e, int n_live, double* host5)
+__global__ __launch_bounds__(256) void tree_potential_sum_kernel(const S4* __restrict__ posm, const S4* __restrict__ acc, int n_live,
+                                                                 double* __restrict__ out)
+{
+    double v = 0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n_live; i += gridDim.x * 256) v += (double)posm[i].w * (double)acc[i].w;
+    v = block_sum(v);
+    if (threadIdx.x == 0) atomicAdd(&out[4], v);
+}
+
+// Bodies up to which the potential is the exact fp64 pair sum; above it tree mode sums the potential over the
+// nodes the walk accepts (same theta as the forces), and direct mode refuses.
+#define ENERGY_PAIR_SUM_MAX 262144
+
+template <typename S4>
+static int energy_t(nbe_engine* e, int n_live, bool tree_potential, double* host5)
 {
     if (!e->d_energy) NBE_HIP(hipMalloc((void**)&e->d_energy, 8 * sizeof(double)));
     NBE_HIP(hipMemsetAsync(e->d_energy, 0, 8 * sizeof(double), e->stream));
@@ -78,8 +94,12 @@ static int energy_t(nbe_engine* e, int n_live, double* host5)
         if (kb > 1024) kb = 1024;
         hipLaunchKernelGGL((kinetic_kernel<S4>), dim3(kb), dim3(256), 0, e->stream, (const S4*)e->posm[e->cur],
                            (const S4*)e->vel[e->cur], n_live, e->d_energy);
-        hipLaunchKernelGGL((potential_kernel<S4>), dim3(cdiv(n_live, 256)), dim3(256), 0, e->stream,
-                           (const S4*)e->posm[e->cur], n_live, e->cfg.eps * e->cfg.eps, e->d_energy);
+        if (tree_potential)
+            hipLaunchKernelGGL((tree_potential_sum_kernel<S4>), dim3(kb), dim3(256), 0, e->stream, (const S4*)e->posm[e->cur],
+                               (const S4*)e->acc, n_live, e->d_energy);
+        else
+            hipLaunchKernelGGL((potential_kernel<S4>), dim3(cdiv(n_live, 256)), dim3(256), 0, e->stream,
+                               (const S4*)e->posm[e->cur], n_live, e->cfg.eps * e->cfg.eps, e->d_energy);
         NBE_HIP(hipGetLastError());
     }
     NBE_HIP(hipMemcpyAsync(host5, e->d_energy, 5 * sizeof(double), hipMemcpyDeviceToHost, e->stream));
@@ -89,6 +109,16 @@ static int energy_t(nbe_engine* e, int n_live, double* host5)
 
 int energy_compute(nbe_engine* e, double* ke, double* pe, double mom[3])
 {
+    const bool tree_potential = e->cfg.mode == NBE_MODE_TREE && e->n > ENERGY_PAIR_SUM_MAX;
+    if (!tree_potential && e->n > ENERGY_PAIR_SUM_MAX * 16) {
+        nbe_set_error("nbe_energy in direct mode sums all pairs in fp64 and is limited to %d bodies", ENERGY_PAIR_SUM_MAX * 16);
+        return NBE_E_UNSUPPORTED;
+    }
+    if (tree_potential) {
+        // instrumented walk over the current state: leaves each body's potential in e->acc[i].w
+        if (!e->prepared) { NBE_TRY(tree_sort_and_build(e)); e->prepared = true; }
+        NBE_TRY(tree_forces(e, e->cur, 0, e->n, false, true, e->cur ^ 1));
+    }
     int n_live = (int)e->n;
     if (e->have_counts) {
         int c[4];
@@ -97,8 +127,8 @@ int energy_compute(nbe_engine* e, double* ke, double* pe, double mom[3])
         n_live = c[0];
     }
     double h[5] = {0, 0, 0, 0, 0};
-    if (e->state64) NBE_TRY((energy_t<double4>(e, n_live, h)));
-    else NBE_TRY((energy_t<float4>(e, n_live, h)));
+    if (e->state64) NBE_TRY((energy_t<double4>(e, n_live, tree_potential, h)));
+    else NBE_TRY((energy_t<float4>(e, n_live, tree_potential, h)));
     if (ke) *ke = h[0];
     if (mom) { mom[0] = h[1]; mom[1] = h[2]; mom[2] = h[3]; }
     if (pe) *pe = -0.5 * e->cfg.G * h[4];

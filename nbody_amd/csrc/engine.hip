@@ -449,7 +449,6 @@ extern "C" int nbe_energy(nbe_engine* e, double* kinetic, double* potential, dou
     if (!e) { nbe_set_error("engine is NULL"); return NBE_E_INVALID; }
     NBE_TRY(use_device(e));
     if (e->advance_pending) { nbe_set_error("nbe_energy between nbe_shard_advance and nbe_shard_commit"); return NBE_E_INVALID; }
-    if (e->n > 4u * 1024u * 1024u) { nbe_set_error("nbe_energy sums all pairs in fp64 and is limited to 4M bodies"); return NBE_E_UNSUPPORTED; }
     return energy_compute(e, kinetic, potential, momentum);
 }
 

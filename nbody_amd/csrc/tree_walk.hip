@@ -55,8 +55,9 @@ __device__ __forceinline__ double as_real(unsigned long long v) { return __longl
 __device__ __forceinline__ bool node_opens(const RawF& nd, float r2, float) { return r2 < as_real(nd.w2); }
 __device__ __forceinline__ bool node_opens(const RawD& nd, double r2, double theta) { return as_real(nd.w) / sqrt(r2) > theta; }
 
-// COUNT: also count the force evaluations (tree.go:232-238 executions) of the wave; the production step
-// runs without it.
+// COUNT: instrumented pass: also counts the force evaluations (tree.go:232-238 executions) of the wave and sums
+// each body's potential (sum of mass / softened distance over the same accepted nodes, returned in the w
+// component of the acceleration record, without the factor -G); the production step runs without it.
 // SOFT: Plummer softening is on, so the opening test must undo the eps^2 folded into r^2 (with eps = 0 the
 // floor is 1e-12 m^2, far below the resolution of any cell edge, and the test uses r^2 as is).
 template <typename R, typename A, typename NodeT, int OUT, bool COUNT, bool SOFT>
@@ -83,6 +84,7 @@ __global__ __launch_bounds__(256) void walk_kernel(
     A ax = 0, ay = 0, az = 0;
     int my_skip = valid ? 0 : 0x7fffffff;        // the lane sits out while cursor < my_skip
     unsigned count = 0;
+    A phi = 0;
     int it = 0;
     // The cursor and the node under it live in scalar registers: one scalar load per visit.  Measured
     // alternatives that fetch both possible successors ahead of the vote were slower: the scalar unit is
@@ -107,7 +109,11 @@ __global__ __launch_bounds__(256) void walk_kernel(
         fx = fma(dx, w, fx);
         fy = fma(dy, w, fy);
         fz = fma(dz, w, fz);
-        if (COUNT) count += (unsigned)__popcll(__builtin_amdgcn_ballot_w64(take && (dx != (R)0 || dy != (R)0 || dz != (R)0)));
+        if (COUNT) {
+            const bool use = take && (dx != (R)0 || dy != (R)0 || dz != (R)0);
+            count += (unsigned)__popcll(__builtin_amdgcn_ballot_w64(use));
+            if (use) phi += (A)(rinv * as_real(nd.m));
+        }
         cur = __builtin_amdgcn_ballot_w64(open) != 0 ? cur + 1 : skip;
         if (BLOCKED && ((++it) & 63) == 0) {
             ax += (A)fx; ay += (A)fy; az += (A)fz;
@@ -119,7 +125,7 @@ __global__ __launch_bounds__(256) void walk_kernel(
     if (COUNT && (threadIdx.x & 63) == 0 && interactions) atomicAdd(interactions, (unsigned long long)count);
     if (!valid) return;
     if (OUT == OUT_ACC) {
-        A4 o; o.x = G * ax; o.y = G * ay; o.z = G * az; o.w = 0;
+        A4 o; o.x = G * ax; o.y = G * ay; o.z = G * az; o.w = phi;
         acc_out[i] = o;
     } else {
         kick_drift<A>(i, G * ax, G * ay, G * az, dt, pos_in, vel_in, pos_out, vel_out, mirror_out);

@@ -132,3 +132,21 @@ def test_frame_stream_delivers_the_state_before_each_step(gpu, mode, precision):
         assert np.array_equal(ids[order], want_ids)
         assert np.array_equal(xyzm[order, :3], p.astype(np.float32))
         assert np.array_equal(xyzm[order, 3], m.astype(np.float32))
+
+
+def test_tree_potential_at_scale_matches_pair_sum(gpu):
+    """Above 262,144 bodies nbe_energy takes the potential from the tree walk (same acceptance as the forces).
+    On a 300k-body Plummer sphere it must agree with the exact pair sum of the direct engine to 2e-3, and the
+    virial ratio 2K/|W| of the sampled sphere must be near 1."""
+    b = physics.plummer(300000, seed=9)
+    with Engine(mode="tree", precision="f32", theta=0.5, eps=1.0) as e:
+        e.upload(b.pos, b.vel, b.mass)
+        ke_t, pe_t, mom_t = e.energy()
+        e.step(1)                           # the walk state left by energy() must not disturb stepping
+        assert e.stats().n_alive == len(b)
+    with Engine(mode="direct", precision="f32", eps=1.0) as e:
+        e.upload(b.pos, b.vel, b.mass)
+        ke_d, pe_d, mom_d = e.energy()
+    assert abs(ke_t - ke_d) <= 1e-9 * ke_d
+    assert abs(pe_t - pe_d) <= 2e-3 * abs(pe_d)
+    assert abs(2 * ke_d / abs(pe_d) - 1.0) < 0.02
