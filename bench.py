@@ -212,6 +212,33 @@ def main():
                                                      "interactions_per_s": float(t.item()) * 5 / s3}
             e3.close()
 
+    if not args.no_extra and world == 1:
+        # BASELINE config 2: 65,536-body uniform cloud, fp32 direct sum
+        u = physics.uniform_cube(65536, seed=1)
+        e4 = Engine(mode="direct", precision="f32", device=local)
+        e4.upload(u.pos, u.vel, u.mass)
+        e4.set_stream(torch.cuda.current_stream().cuda_stream)
+        s4 = timed_steps(lambda: e4.step(1), sync, barrier, 5, 50)
+        kms4 = e4.time_force_kernel(5)
+        extra["direct_fp32_uniform_64k"] = {"ms_per_step": 1e3 * s4 / 50, "interactions_per_s": 65536 * 65535 * 50 / s4,
+                                            "force_kernel_ms": kms4,
+                                            "force_kernel_frac_of_fp32_valu_peak": 65536 * 65535 * FLOP_PER_INTERACTION / (kms4 * 1e-3) / 1e12 / FP32_VALU_PEAK_TFLOPS}
+        e4.close()
+        # BASELINE config 1: the reference's default scene (main.go:32-37: 1000 bodies + 2 cores), tree, theta = 1
+        g = physics.makebodies(1000, seed=1)
+        e5 = Engine(mode="tree", precision="f32", theta=1.0, device=local)
+        e5.upload(g.pos, g.vel, g.mass)
+        e5.set_stream(torch.cuda.current_stream().cuda_stream)
+        s5 = timed_steps(lambda: e5.step(1), sync, barrier, 10, 100)
+        extra["default_scene_1002_tree_theta1"] = {"gpu_ms_per_step": 1e3 * s5 / 100}
+        e5.close()
+        if rank == 0 and not args.no_cpu_baseline:
+            from oracle import oracle as O
+            t0 = time.perf_counter()
+            O.step(g.mass, g.pos, g.vel, nsteps=100, mode="tree", com_mode="ref", theta=1.0, drop_tail=True, groups=4)
+            extra["default_scene_1002_tree_theta1"]["cpu_port_ms_per_step"] = 1e3 * (time.perf_counter() - t0) / 100
+            extra["default_scene_1002_tree_theta1"]["cpu_port_note"] = "C port of main.go:129-178 as written: serial build, 4 walk threads, reference COM update, last N mod 4 bodies unwalked"
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline_direct(args.cpu_sample) if headline_mode == "direct" else None

@@ -474,6 +474,12 @@ __global__ __launch_bounds__(256) void emit_nodes_kernel(int n, int* __restrict_
         const int cells = na > 0 ? (int)cellcnt[na] : 0;
         counters[1] = na + cells;
         counters[2] = cells;
+        // sentinel behind the last node: massless, never opens, skips to itself (a finished walk parks here)
+        NodeT snt;
+        snt.x = 0; snt.y = 0; snt.z = 0; snt.m = 0;
+        set_edge<NodeT>(snt, 0.0, theta);
+        snt.skip = na + cells;
+        nodes[na + cells] = snt;
     }
     if (t < n) {
         if (t >= na) return;

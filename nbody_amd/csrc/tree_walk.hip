@@ -26,10 +26,12 @@ struct RawD { unsigned long long x, y, z, m, w; int skip; };
 __device__ __forceinline__ RawF load_raw(const NodeF* __restrict__ nodes, int i)
 {
     // 32-bit byte offset from the array base: the scalar load takes it as an SGPR offset (no 64-bit adds)
+    // one 32-byte, 32-byte-aligned request (s_load_dwordx8): the scalar cache sustains few misses in flight,
+    // so requests per visit matter more than bytes
+    typedef unsigned u8v __attribute__((ext_vector_type(8)));
     const char* base = reinterpret_cast<const char*>(nodes) + (size_t)((unsigned)i * 32u);
-    const uint4 a = *reinterpret_cast<const uint4*>(base);
-    const uint2 b = *reinterpret_cast<const uint2*>(base + 16);
-    return RawF{a.x, a.y, a.z, a.w, b.x, (int)b.y};
+    const u8v a = *reinterpret_cast<const u8v*>(__builtin_assume_aligned(base, 32));
+    return RawF{a[0], a[1], a[2], a[3], a[4], (int)a[5]};
 }
 __device__ __forceinline__ RawD load_raw(const NodeD* __restrict__ nodes, int i)
 {
@@ -60,7 +62,15 @@ __device__ __forceinline__ bool node_opens(const RawD& nd, double r2, double the
 // component of the acceleration record, without the factor -G); the production step runs without it.
 // SOFT: Plummer softening is on, so the opening test must undo the eps^2 folded into r^2 (with eps = 0 the
 // floor is 1e-12 m^2, far below the resolution of any cell edge, and the test uses r^2 as is).
-template <typename R, typename A, typename NodeT, int OUT, bool COUNT, bool SOFT>
+// NS: independent traversals (groups of 64 bodies) interleaved in one wave, each with its own cursor, node
+// registers and sit-out index; a group that finishes first parks on the sentinel record behind the last node
+// (mass 0, skip = itself).  Measured at 1M / 4M bodies: NS = 1: 2.21 / 8.53 ms, NS = 2: 2.31 / 8.21 ms,
+// NS = 3: 3.0 / 9.5 ms, so NS = 1 ships.  What bounds the kernel (rocprofv3 counters, 1M-body Plummer sphere,
+// theta = 0.5): 6.5e7 node visits per pass, one 32-byte scalar load each; the scalar data cache serves only
+// 29 % of them (SQC_DCACHE_HITS / REQ), the rest go to L2 (97 % hits after the XCD remap below), and waves sit
+// in s_waitcnt for 47 % of their cycles even at 8 waves per SIMD: the limit is the scalar cache's miss
+// throughput, not arithmetic (16 VALU + 8 SALU instructions per visit) and not HBM.
+template <typename R, typename A, typename NodeT, int OUT, bool COUNT, bool SOFT, int NS>
 __global__ __launch_bounds__(256) void walk_kernel(
     const NodeT* __restrict__ nodes, const int* __restrict__ counters, const typename V4<R>::type* __restrict__ posm,
     int t0, int t1, R theta, R floor2, A G, A dt, typename V4<A>::type* __restrict__ acc_out,
@@ -74,61 +84,87 @@ __global__ __launch_bounds__(256) void walk_kernel(
     const int na = counters[0];
     const int total = counters[1];
     const int tend = t1 < na ? t1 : na;
-    const int i = t0 + blockIdx.x * 256 + threadIdx.x;
-    const bool valid = i < tend;
-    if (__ballot(valid) == 0) return;            // whole wave past the end
+    // Workgroups are dealt round-robin to the 8 XCDs, each with its own 4 MB L2.  Remap so that the
+    // workgroups of one XCD own one contiguous eighth of the Morton-ordered bodies: their walks then share
+    // the same near-field nodes in that L2 instead of every XCD streaming the whole tree (bijective for any
+    // grid size; a placement assumption that only affects speed).
+    const unsigned nwg = gridDim.x, q8 = nwg / 8, r8 = nwg % 8, xcd = blockIdx.x % 8;
+    const unsigned wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + blockIdx.x / 8;
+    const int ibase = t0 + (int)wg * (256 * NS) + threadIdx.x;
+    if (__ballot(ibase < tend) == 0) return;     // whole wave past the end (group 0 holds its lowest bodies)
 
-    R px = 0, py = 0, pz = 0;
-    if (valid) { R4 p = posm[i]; px = p.x; py = p.y; pz = p.z; }
-    R fx = 0, fy = 0, fz = 0;
-    A ax = 0, ay = 0, az = 0;
-    int my_skip = valid ? 0 : 0x7fffffff;        // the lane sits out while cursor < my_skip
+    bool valid[NS];
+    R px[NS], py[NS], pz[NS], fx[NS], fy[NS], fz[NS];
+    A ax[NS], ay[NS], az[NS], phi[NS];
+    int my_skip[NS];                             // the lane sits out while cursor < my_skip
+    int cur[NS];
     unsigned count = 0;
-    A phi = 0;
+#pragma unroll
+    for (int s = 0; s < NS; s++) {
+        const int i = ibase + s * 256;
+        valid[s] = i < tend;
+        px[s] = 0; py[s] = 0; pz[s] = 0;
+        if (valid[s]) { R4 p = posm[i]; px[s] = p.x; py[s] = p.y; pz[s] = p.z; }
+        fx[s] = 0; fy[s] = 0; fz[s] = 0; ax[s] = 0; ay[s] = 0; az[s] = 0; phi[s] = 0;
+        my_skip[s] = valid[s] ? 0 : 0x7fffffff;
+        cur[s] = __ballot(valid[s]) != 0 ? 0 : total;     // a group without bodies starts parked
+    }
     int it = 0;
-    // The cursor and the node under it live in scalar registers: one scalar load per visit.  Measured
-    // alternatives that fetch both possible successors ahead of the vote were slower: the scalar unit is
-    // shared by the CU's four SIMDs, so the extra loads and selects cost more than the latency they hide
-    // (8 waves per SIMD already cover it).
-    int cur = 0;
-    while (cur < total) {
-        const auto nd = load_raw(nodes, cur);
-        const int skip = nd.skip;
-        const R dx = as_real(nd.x) - px, dy = as_real(nd.y) - py, dz = as_real(nd.z) - pz;
-        // The floor under r^2 (1e-12 m^2 unless softening is on) keeps rsq finite for the body's own leaf and
-        // for bodies at distance 0, which then contribute exactly 0 because dx = dy = dz = 0.
-        const R r2 = fma(dx, dx, fma(dy, dy, fma(dz, dz, floor2)));
-        const bool active = cur >= my_skip;
-        // lanes sitting out get an infinite distance, so one compare is both the opening test and the vote
-        const R rtest = active ? (SOFT ? r2 - floor2 : r2) : (R)INFINITY;
-        const bool open = node_opens(nd, rtest, theta);
-        const bool take = active && !open;
-        if (take) my_skip = skip;
-        const R rinv = rsq_dev(r2);
-        const R w = take ? (rinv * rinv) * (rinv * as_real(nd.m)) : (R)0;
-        fx = fma(dx, w, fx);
-        fy = fma(dy, w, fy);
-        fz = fma(dz, w, fz);
-        if (COUNT) {
-            const bool use = take && (dx != (R)0 || dy != (R)0 || dz != (R)0);
-            count += (unsigned)__popcll(__builtin_amdgcn_ballot_w64(use));
-            if (use) phi += (A)(rinv * as_real(nd.m));
+    // Cursors and the nodes under them live in scalar registers: one scalar load per visit and group.
+    // (Fetching both possible successors ahead of the vote was slower: the scalar unit is shared by the CU's
+    // four SIMDs, and the extra loads and selects cost more than the latency they hid.)
+    for (;;) {
+        bool more = false;
+#pragma unroll
+        for (int s = 0; s < NS; s++) more = more || cur[s] < total;
+        if (!more) break;
+#pragma unroll
+        for (int s = 0; s < NS; s++) {
+            const auto nd = load_raw(nodes, cur[s]);
+            const int skip = nd.skip;
+            const R dx = as_real(nd.x) - px[s], dy = as_real(nd.y) - py[s], dz = as_real(nd.z) - pz[s];
+            // The floor under r^2 (1e-12 m^2 unless softening is on) keeps rsq finite for the body's own leaf
+            // and for bodies at distance 0, which then contribute exactly 0 because dx = dy = dz = 0.
+            const R r2 = fma(dx, dx, fma(dy, dy, fma(dz, dz, floor2)));
+            const bool active = cur[s] >= my_skip[s];
+            // lanes sitting out get an infinite distance, so one compare is both the opening test and the vote
+            const R rtest = active ? (SOFT ? r2 - floor2 : r2) : (R)INFINITY;
+            const bool open = node_opens(nd, rtest, theta);
+            const bool take = active && !open;
+            if (take) my_skip[s] = skip;
+            const R rinv = rsq_dev(r2);
+            const R w = take ? (rinv * rinv) * (rinv * as_real(nd.m)) : (R)0;
+            fx[s] = fma(dx, w, fx[s]);
+            fy[s] = fma(dy, w, fy[s]);
+            fz[s] = fma(dz, w, fz[s]);
+            if (COUNT) {
+                const bool use = take && cur[s] < total && (dx != (R)0 || dy != (R)0 || dz != (R)0);
+                count += (unsigned)__popcll(__builtin_amdgcn_ballot_w64(use));
+                if (use) phi[s] += (A)(rinv * as_real(nd.m));
+            }
+            cur[s] = __builtin_amdgcn_ballot_w64(open) != 0 ? cur[s] + 1 : skip;
         }
-        cur = __builtin_amdgcn_ballot_w64(open) != 0 ? cur + 1 : skip;
         if (BLOCKED && ((++it) & 63) == 0) {
-            ax += (A)fx; ay += (A)fy; az += (A)fz;
-            fx = 0; fy = 0; fz = 0;
+#pragma unroll
+            for (int s = 0; s < NS; s++) {
+                ax[s] += (A)fx[s]; ay[s] += (A)fy[s]; az[s] += (A)fz[s];
+                fx[s] = 0; fy[s] = 0; fz[s] = 0;
+            }
         }
     }
-    ax += (A)fx; ay += (A)fy; az += (A)fz;
 
     if (COUNT && (threadIdx.x & 63) == 0 && interactions) atomicAdd(interactions, (unsigned long long)count);
-    if (!valid) return;
-    if (OUT == OUT_ACC) {
-        A4 o; o.x = G * ax; o.y = G * ay; o.z = G * az; o.w = phi;
-        acc_out[i] = o;
-    } else {
-        kick_drift<A>(i, G * ax, G * ay, G * az, dt, pos_in, vel_in, pos_out, vel_out, mirror_out);
+#pragma unroll
+    for (int s = 0; s < NS; s++) {
+        if (!valid[s]) continue;
+        const int i = ibase + s * 256;
+        const A sx = ax[s] + (A)fx[s], sy = ay[s] + (A)fy[s], sz = az[s] + (A)fz[s];
+        if (OUT == OUT_ACC) {
+            A4 o; o.x = G * sx; o.y = G * sy; o.z = G * sz; o.w = phi[s];
+            acc_out[i] = o;
+        } else {
+            kick_drift<A>(i, G * sx, G * sy, G * sz, dt, pos_in, vel_in, pos_out, vel_out, mirror_out);
+        }
     }
 }
 
@@ -148,8 +184,11 @@ __global__ __launch_bounds__(256) void carry_dead_kernel(const int* __restrict__
     if (mirror_in) mirror_out[i] = mirror_in[i];
 }
 
+#ifndef WALK_NS
+#define WALK_NS 1
+#endif
 #define WALK_LAUNCH(...)                                                                                     \
-    hipLaunchKernelGGL((soft ? walk_kernel<R, A, NodeT, __VA_ARGS__, true> : walk_kernel<R, A, NodeT, __VA_ARGS__, false>),
+    hipLaunchKernelGGL((soft ? walk_kernel<R, A, NodeT, __VA_ARGS__, true, WALK_NS> : walk_kernel<R, A, NodeT, __VA_ARGS__, false, WALK_NS>),
 
 template <typename R, typename A, typename NodeT>
 static int launch_walk(nbe_engine* e, const void* src, uint64_t t0, uint64_t t1, bool fused, bool count, int src_buf, int dst_buf)
@@ -169,20 +208,22 @@ static int launch_walk(nbe_engine* e, const void* src, uint64_t t0, uint64_t t1,
     A4* pos_out = (A4*)e->posm[dst_buf];
     A4* vel_out = (A4*)e->vel[dst_buf];
     float4* mirror_out = mixed ? e->mirror[dst_buf] : nullptr;
-    dim3 grid(cdiv(nt, 256));
+    dim3 grid(cdiv(nt, 256 * WALK_NS));
+    dim3 cgrid(cdiv(nt, 256));
+    const unsigned dbg_lds = getenv("NBE_WALK_LDS") ? (unsigned)atoi(getenv("NBE_WALK_LDS")) : 0;   // occupancy experiment
     if (fused) {
-        WALK_LAUNCH(OUT_FUSED, false) grid, dim3(256), 0, e->stream, (const NodeT*)e->tw.nodes,
+        WALK_LAUNCH(OUT_FUSED, false) grid, dim3(256), dbg_lds, e->stream, (const NodeT*)e->tw.nodes,
                            e->tw.counters, (const R4*)src, (int)t0, (int)t1, (R)e->cfg.theta, floor2, G, dt, (A4*)e->acc,
                            pos_in, vel_in, pos_out, vel_out, mirror_out, e->tw.d_interactions);
-        hipLaunchKernelGGL((carry_dead_kernel<A4>), grid, dim3(256), 0, e->stream, e->tw.counters, (int)t0, (int)t1, pos_in,
+        hipLaunchKernelGGL((carry_dead_kernel<A4>), cgrid, dim3(256), 0, e->stream, e->tw.counters, (int)t0, (int)t1, pos_in,
                            vel_in, mixed ? e->mirror[src_buf] : (const float4*)nullptr, pos_out, vel_out, mirror_out);
     } else if (count) {
         NBE_HIP(hipMemsetAsync(e->tw.d_interactions, 0, 8 * sizeof(unsigned long long), e->stream));
-        WALK_LAUNCH(OUT_ACC, true) grid, dim3(256), 0, e->stream, (const NodeT*)e->tw.nodes,
+        WALK_LAUNCH(OUT_ACC, true) grid, dim3(256), dbg_lds, e->stream, (const NodeT*)e->tw.nodes,
                            e->tw.counters, (const R4*)src, (int)t0, (int)t1, (R)e->cfg.theta, floor2, G, dt, (A4*)e->acc,
                            pos_in, vel_in, pos_out, vel_out, mirror_out, e->tw.d_interactions);
     } else {
-        WALK_LAUNCH(OUT_ACC, false) grid, dim3(256), 0, e->stream, (const NodeT*)e->tw.nodes,
+        WALK_LAUNCH(OUT_ACC, false) grid, dim3(256), dbg_lds, e->stream, (const NodeT*)e->tw.nodes,
                            e->tw.counters, (const R4*)src, (int)t0, (int)t1, (R)e->cfg.theta, floor2, G, dt, (A4*)e->acc,
                            pos_in, vel_in, pos_out, vel_out, mirror_out, e->tw.d_interactions);
     }
