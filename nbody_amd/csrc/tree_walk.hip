@@ -210,20 +210,19 @@ static int launch_walk(nbe_engine* e, const void* src, uint64_t t0, uint64_t t1,
     float4* mirror_out = mixed ? e->mirror[dst_buf] : nullptr;
     dim3 grid(cdiv(nt, 256 * WALK_NS));
     dim3 cgrid(cdiv(nt, 256));
-    const unsigned dbg_lds = getenv("NBE_WALK_LDS") ? (unsigned)atoi(getenv("NBE_WALK_LDS")) : 0;   // occupancy experiment
     if (fused) {
-        WALK_LAUNCH(OUT_FUSED, false) grid, dim3(256), dbg_lds, e->stream, (const NodeT*)e->tw.nodes,
+        WALK_LAUNCH(OUT_FUSED, false) grid, dim3(256), 0, e->stream, (const NodeT*)e->tw.nodes,
                            e->tw.counters, (const R4*)src, (int)t0, (int)t1, (R)e->cfg.theta, floor2, G, dt, (A4*)e->acc,
                            pos_in, vel_in, pos_out, vel_out, mirror_out, e->tw.d_interactions);
         hipLaunchKernelGGL((carry_dead_kernel<A4>), cgrid, dim3(256), 0, e->stream, e->tw.counters, (int)t0, (int)t1, pos_in,
                            vel_in, mixed ? e->mirror[src_buf] : (const float4*)nullptr, pos_out, vel_out, mirror_out);
     } else if (count) {
         NBE_HIP(hipMemsetAsync(e->tw.d_interactions, 0, 8 * sizeof(unsigned long long), e->stream));
-        WALK_LAUNCH(OUT_ACC, true) grid, dim3(256), dbg_lds, e->stream, (const NodeT*)e->tw.nodes,
+        WALK_LAUNCH(OUT_ACC, true) grid, dim3(256), 0, e->stream, (const NodeT*)e->tw.nodes,
                            e->tw.counters, (const R4*)src, (int)t0, (int)t1, (R)e->cfg.theta, floor2, G, dt, (A4*)e->acc,
                            pos_in, vel_in, pos_out, vel_out, mirror_out, e->tw.d_interactions);
     } else {
-        WALK_LAUNCH(OUT_ACC, false) grid, dim3(256), dbg_lds, e->stream, (const NodeT*)e->tw.nodes,
+        WALK_LAUNCH(OUT_ACC, false) grid, dim3(256), 0, e->stream, (const NodeT*)e->tw.nodes,
                            e->tw.counters, (const R4*)src, (int)t0, (int)t1, (R)e->cfg.theta, floor2, G, dt, (A4*)e->acc,
                            pos_in, vel_in, pos_out, vel_out, mirror_out, e->tw.d_interactions);
     }

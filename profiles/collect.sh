@@ -1,9 +1,9 @@
 #!/bin/bash
 # Collects the rocprofv3 evidence behind bench.py's numbers.  Run on the GPU box from the repository root:
 #   bash profiles/collect.sh r01
-# Pass 1: kernel trace + stats of the default bench command.  Passes 2 and 3: HBM traffic counters of the
-# headline direct-sum run and of the Barnes-Hut run, each counter group in a run of its own (no tracing
-# domains together with --pmc).  Outputs land in gpurun_out/prof_<tag>/ ; summarise.py condenses them into
+# Passes 1-2: kernel trace + stats of the headline bench command (1M-body direct sum) and of the Barnes-Hut
+# workload.  Later passes: HBM traffic and SQ counters of both, each counter group in a run of its own (no
+# tracing domains together with --pmc).  Outputs land in gpurun_out/prof_<tag>/ ; summarise.py condenses them into
 # profiles/<tag>_*.txt and profiles/traffic.json, which are the files that get committed.
 set -u
 TAG=${1:-r01}
@@ -11,7 +11,9 @@ OUT=gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 run() { echo "== $*" >&2; timeout -s KILL "$@"; }
-run 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/bench_trace.json" 2> "$OUT/bench_trace.err" || exit 1
+rm -rf "$OUT"; mkdir -p "$OUT"
+run 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_direct" -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extra > "$OUT/bench_trace_direct.json" 2> "$OUT/bench_trace_direct.err" || exit 1
+run 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_tree" -- python3 bench.py --workload tree --steps 20 --warmup 2 --no-cpu-baseline --no-extra > "$OUT/bench_trace_tree.json" 2> "$OUT/bench_trace_tree.err" || exit 1
 run 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch_direct" -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extra > /dev/null 2> "$OUT/pmc1.err" || exit 1
 run 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write_direct" -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extra > /dev/null 2> "$OUT/pmc2.err" || exit 1
 run 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch_tree" -- python3 bench.py --workload tree --steps 2 --warmup 1 --no-cpu-baseline --no-extra > /dev/null 2> "$OUT/pmc3.err" || exit 1

@@ -28,24 +28,28 @@ def short(name):
     for k in ("direct_kernel", "direct_finish_kernel", "walk_kernel", "radix_scatter_kernel", "radix_hist_kernel",
               "scan_reduce_kernel", "scan_sums_kernel", "scan_apply_kernel", "keys_kernel", "permute_kernel",
               "radix_tree_kernel", "mark_cells_kernel", "emit_nodes_kernel", "cell_mass_kernel", "carry_dead_kernel",
-              "refresh_mirror_kernel", "kinetic_kernel", "potential_kernel"):
+              "refresh_mirror_kernel", "kinetic_kernel", "potential_kernel", "psum_apply_kernel", "psum_reduce_kernel",
+              "psum_scan_sums_kernel", "set_alive_count_kernel"):
         if k in name:
             return k
     return name[:60]
 
 
-# ---- kernel trace ----
-agg = defaultdict(lambda: [0, 0.0, 1e30, 0.0])
-for r in rows("trace/**/*kernel_trace.csv"):
-    d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3   # us
-    a = agg[short(r["Kernel_Name"])]
-    a[0] += 1; a[1] += d; a[2] = min(a[2], d); a[3] = max(a[3], d)
-total = sum(a[1] for a in agg.values()) or 1.0
+# ---- kernel traces ----
 with open(os.path.join(root, "profiles", f"{tag}_kernel_stats.txt"), "w") as f:
-    f.write(f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline   (tag {tag})\n")
-    f.write(f"{'kernel':28s} {'calls':>7s} {'total_us':>14s} {'avg_us':>12s} {'min_us':>12s} {'max_us':>12s} {'share':>7s}\n")
-    for k, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-        f.write(f"{k:28s} {a[0]:7d} {a[1]:14.1f} {a[1] / a[0]:12.2f} {a[2]:12.2f} {a[3]:12.2f} {100 * a[1] / total:6.2f}%\n")
+    for sub, cmd in (("trace_direct", "python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extra"),
+                     ("trace_tree", "python3 bench.py --workload tree --steps 20 --warmup 2 --no-cpu-baseline --no-extra")):
+        agg = defaultdict(lambda: [0, 0.0, 1e30, 0.0])
+        for r in rows(f"{sub}/**/*kernel_trace.csv"):
+            d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3   # us
+            a = agg[short(r["Kernel_Name"])]
+            a[0] += 1; a[1] += d; a[2] = min(a[2], d); a[3] = max(a[3], d)
+        total = sum(a[1] for a in agg.values()) or 1.0
+        f.write(f"# rocprofv3 --kernel-trace --stats -- {cmd}   (tag {tag})\n")
+        f.write(f"{'kernel':28s} {'calls':>7s} {'total_us':>14s} {'avg_us':>12s} {'min_us':>12s} {'max_us':>12s} {'share':>7s}\n")
+        for k, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+            f.write(f"{k:28s} {a[0]:7d} {a[1]:14.1f} {a[1] / a[0]:12.2f} {a[2]:12.2f} {a[3]:12.2f} {100 * a[1] / total:6.2f}%\n")
+        f.write("\n")
 
 # ---- counters ----
 pmc = defaultdict(lambda: defaultdict(lambda: [0, 0.0]))
