@@ -208,13 +208,16 @@ __global__ __launch_bounds__(256) void radix_hist_kernel(const uint64_t* __restr
 
 // Stable scatter.  Each wave owns a contiguous quarter of the tile and walks it 64 keys at a time; within a
 // round, lanes holding the same digit find each other with 8 ballots, and a per-wave digit counter in LDS
-// carries the running count across rounds.
+// carries the running count across rounds.  The tile is then reordered in LDS and written out in runs.
 __global__ __launch_bounds__(256) void radix_scatter_kernel(const uint64_t* __restrict__ kin, const uint32_t* __restrict__ vin,
                                                             uint64_t* __restrict__ kout, uint32_t* __restrict__ vout,
                                                             const uint32_t* __restrict__ offsets, int n, int shift, int nblocks)
 {
     __shared__ uint32_t wcount[4][256];
     __shared__ uint32_t wbase[4][256];
+    __shared__ uint32_t dbase[256], gdelta[256];
+    __shared__ uint64_t skey[SORT_TILE];
+    __shared__ uint32_t sval[SORT_TILE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #pragma unroll
     for (int w = 0; w < 4; w++) wcount[w][tid] = 0;
@@ -245,20 +248,46 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const uint64_t* __re
         if (valid && (peers & lt_mask) == 0) wc[digit] = prior + (uint32_t)__popcll(peers);
     }
     __syncthreads();
+    // Per digit: offsets of the four waves within the digit, the digit's count in this tile, and (after the
+    // scan) the digit's first slot in the tile's digit-sorted order.
+    uint32_t dcount;
     {
         uint32_t run = 0;
 #pragma unroll
         for (int w = 0; w < 4; w++) { wbase[w][tid] = run; run += wcount[w][tid]; }
+        dcount = run;
+    }
+    {
+        uint32_t tot;
+        const uint32_t dstart = block_excl_scan(dcount, &tot);     // contains the barriers that publish wbase
+        dbase[tid] = dstart;
+        // where this digit's run goes in the output, minus its first slot in the tile: global = slot + gdelta
+        gdelta[tid] = offsets[(size_t)tid * nblocks + blockIdx.x] - dstart;
     }
     __syncthreads();
+    // Stage the tile in digit-sorted order in LDS, then write it out with consecutive threads on consecutive
+    // slots: slots of one digit are consecutive in the output too, so the stores coalesce into runs instead
+    // of 8- and 4-byte scattered writes.
 #pragma unroll
     for (int r = 0; r < SORT_KPT; r++) {
         const int i = base + r * 64 + lane;
         if (i < n) {
             const uint32_t digit = (uint32_t)(k[r] >> shift) & 255u;
-            const uint32_t pos = offsets[(size_t)digit * nblocks + blockIdx.x] + wbase[wave][digit] + rank[r];
-            kout[pos] = k[r];
-            vout[pos] = v[r];
+            const uint32_t slot = dbase[digit] + wbase[wave][digit] + rank[r];
+            skey[slot] = k[r];
+            sval[slot] = v[r];
+        }
+    }
+    __syncthreads();
+    const int tile_n = min(SORT_TILE, n - blockIdx.x * SORT_TILE);
+#pragma unroll
+    for (int r = 0; r < SORT_KPT; r++) {
+        const int slot = r * 256 + tid;
+        if (slot < tile_n) {
+            const uint64_t key = skey[slot];
+            const uint32_t pos = (uint32_t)slot + gdelta[(uint32_t)(key >> shift) & 255u];
+            kout[pos] = key;
+            vout[pos] = sval[slot];
         }
     }
 }
