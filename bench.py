@@ -213,7 +213,7 @@ def main():
             e3.close()
 
     if not args.no_extra and world == 1:
-        # BASELINE config 2: 65,536-body uniform cloud, fp32 direct sum
+        # benchmark configuration 2: 65,536-body uniform cloud, fp32 direct sum
         u = physics.uniform_cube(65536, seed=1)
         e4 = Engine(mode="direct", precision="f32", device=local)
         e4.upload(u.pos, u.vel, u.mass)
@@ -224,7 +224,7 @@ def main():
                                             "force_kernel_ms": kms4,
                                             "force_kernel_frac_of_fp32_valu_peak": 65536 * 65535 * FLOP_PER_INTERACTION / (kms4 * 1e-3) / 1e12 / FP32_VALU_PEAK_TFLOPS}
         e4.close()
-        # BASELINE config 1: the reference's default scene (main.go:32-37: 1000 bodies + 2 cores), tree, theta = 1
+        # benchmark configuration 1: the reference's default scene (main.go:32-37: 1000 bodies + 2 cores), tree, theta = 1
         g = physics.makebodies(1000, seed=1)
         e5 = Engine(mode="tree", precision="f32", theta=1.0, device=local)
         e5.upload(g.pos, g.vel, g.mass)

@@ -129,7 +129,7 @@ def test_ten_steps_match_golden(gpu, name, precision, tol, median_tol):
 
 
 def test_64k_uniform_cloud_fp32_against_oracle_sample(gpu):
-    """BASELINE config 2: 65,536 bodies uniform in [-1e4,1e4)^3, m = 1e3, fp32 direct sum; the fp64 oracle
+    """Benchmark configuration 2: 65,536 bodies uniform in [-1e4,1e4)^3, m = 1e3, fp32 direct sum; the fp64 oracle
     is evaluated on a 2,048-target sample against all sources."""
     b = physics.uniform_cube(65536, seed=1)
     pos, mass = f32(b.pos), f32(b.mass)

@@ -26,7 +26,7 @@ def test_energy_matches_oracle(gpu):
 
 @pytest.mark.parametrize("mode,precision", [("direct", "f64"), ("direct", "mixed"), ("tree", "mixed"), ("tree", "f64")])
 def test_energy_and_momentum_drift_two_galaxies(gpu, mode, precision):
-    """Scaled-down BASELINE config 5 (two Plummer spheres on the reference cores' approach course): kick-drift
+    """Scaled-down benchmark configuration 5 (two Plummer spheres on the reference cores' approach course): kick-drift
     Euler with eps = 20 m and dt = 3600 s (dynamical time of each sphere ~ 2e5 s, so dt ~ t_dyn/55).
     Bounds over 300 steps: |dE/E0| <= 2e-3; |dP| / sum m|v| <= 1e-10 for the direct sum (pairwise forces
     cancel up to rounding) and <= 2e-3 for Barnes-Hut at theta = 0.5 (cell forces are not pairwise)."""

@@ -195,7 +195,7 @@ def test_tree_against_fp64_direct_sum(gpu, theta, median_tol, p90_tol):
 
 
 def test_default_scene_100_steps(gpu):
-    """BASELINE config 1: main.go's default galaxy pair (1000 + 2 bodies, theta = 1, dt = 3600), 100 steps,
+    """Benchmark configuration 1: main.go's default galaxy pair (1000 + 2 bodies, theta = 1, dt = 3600), 100 steps,
     fp64 engine against the oracle's tree path (true COM, all bodies walked)."""
     b = physics.makebodies(1000, seed=1)
     with Engine(mode="tree", precision="f64", theta=1.0) as e:
@@ -233,7 +233,7 @@ def test_ten_steps_match_golden(gpu, name, precision, tol, median_tol):
 
 
 def test_1m_plummer_properties(gpu):
-    """BASELINE config 3 size (1,048,576-body Plummer sphere, theta = 0.5): size-independent checks.
+    """Benchmark configuration 3 size (1,048,576-body Plummer sphere, theta = 0.5): size-independent checks.
     (a) every body survives and keeps its identity through the Morton reordering (ids and masses);
     (b) tree accelerations agree with the GPU's own fp32 direct sum: median <= 1e-2, p99 <= 6e-2;
     (c) node bookkeeping: nodes = bodies + cells, cells < bodies;
