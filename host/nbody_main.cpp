@@ -7,8 +7,9 @@
 //   frame loop      main.go:80-190  (frames+1 iterations; a frame copy goes to the workers BEFORE each step)
 //   output workers  main.go:50-61   4 consumers behind a queue of capacity 32 (here fed by nbe_frame_stream_begin)
 //   save / resume   main.go:199-248 (own little-endian binary format; the reference's gob files need Go)
-// The step itself (main.go:104-178) is one nbe_step call.  Collisions are not implemented on the GPU:
-// the program insists on -nocollision, as every benchmark configuration of the reference sets it.
+// The step itself (main.go:104-178) is one nbe_step call.  Collisions run on the GPU in tree mode (the search,
+// queue and merge of tree.go:245-281, main.go:151-167); the direct sum insists on -nocollision, because the
+// engine does not reproduce the order-dependent merge inside the pair loop (main.go:122-126).
 // The reference's sinks are a PNG renderer, a gob chunk store and sqlite; the sink here writes the record the
 // gob store keeps per body (gob.go:54-61: X, Y, Z, Mass, Radius as float32, keyed by ID) as raw binary frames.
 #include <chrono>
@@ -194,14 +195,14 @@ static void frameToFiles(const std::string& dir, FrameQueue* ch)
 
 struct StreamCtx {
     FrameQueue* ch;
-    const std::vector<double>* radius_by_id;   // the engine does not carry radii; they never change without collisions
+    const std::vector<double>* radius_by_id;   // used when the engine sends no radii (collisions off: they never change)
     std::mutex mu;
     std::unique_ptr<frameJob> last;            // lastFrame of main.go:97-100
     int remaining = 0;
 };
 
 // Runs on the engine's delivery thread: turns the streamed arrays into a frameJob and sends it on (main.go:96-101).
-static void on_frame(void* user, int frame, size_t n, const float* xyzm, const uint64_t* ids)
+static void on_frame(void* user, int frame, size_t n, const float* xyzm, const float* radius, const uint64_t* ids)
 {
     StreamCtx* ctx = (StreamCtx*)user;
     auto job = std::make_unique<frameJob>();
@@ -211,7 +212,8 @@ static void on_frame(void* user, int frame, size_t n, const float* xyzm, const u
         body& b = job->Bodies[k];
         b.ID = ids[k];
         b.X = xyzm[4 * k]; b.Y = xyzm[4 * k + 1]; b.Z = xyzm[4 * k + 2]; b.Mass = xyzm[4 * k + 3];
-        b.Radius = ids[k] < ctx->radius_by_id->size() ? (*ctx->radius_by_id)[ids[k]] : 2.0;
+        if (radius) b.Radius = radius[k];
+        else b.Radius = ids[k] < ctx->radius_by_id->size() ? (*ctx->radius_by_id)[ids[k]] : 2.0;
     }
     {
         std::lock_guard<std::mutex> lk(ctx->mu);
@@ -252,7 +254,7 @@ int main(int argc, char** argv)
         else if (a == "-nocollision") nocollision = true;
         else panic("flag provided but not defined: " + a);
     }
-    if (!nocollision) panic("collisions are not implemented on the GPU engine: run with -nocollision");
+    if (!nocollision && !tree) panic("collisions need -tree on the GPU engine: run the direct sum with -nocollision");
 
     const int dt = 60 * 60;                                  // main.go:28
     const int iterPerFrame = 1;                              // main.go:29
@@ -291,6 +293,7 @@ int main(int argc, char** argv)
     cfg.theta = theta;
     cfg.dt = dt;
     cfg.precision = precision;
+    cfg.collisions = nocollision ? 0 : 1;                    // main.go:24
     nbe_engine* eng = nullptr;
     check(nbe_create(&cfg, &eng));
     const size_t n = bodies.size();
@@ -305,6 +308,9 @@ int main(int argc, char** argv)
         radius_by_id[b.ID] = b.Radius;
     }
     check(nbe_upload(eng, n, pos.data(), vel.data(), mass.data(), id.data()));
+    std::vector<double> radius(n);
+    for (size_t k = 0; k < n; k++) radius[k] = bodies[k].Radius;
+    if (cfg.collisions) check(nbe_set_radius(eng, radius.data()));
 
     StreamCtx ctx;
     ctx.ch = &ch;
@@ -344,12 +350,14 @@ int main(int argc, char** argv)
                        // what a resumed run needs.
         size_t alive = 0;
         check(nbe_download(eng, pos.data(), vel.data(), mass.data(), id.data(), &alive));
+        if (cfg.collisions) check(nbe_get_radius(eng, radius.data(), nullptr));
         frameJob fin;
         fin.Frame = frames + 1;
         fin.Bodies.resize(alive);
         for (size_t k = 0; k < alive; k++) {
             body& b = fin.Bodies[k];
-            b.ID = id[k]; b.Mass = mass[k]; b.Radius = id[k] < radius_by_id.size() ? radius_by_id[id[k]] : 2.0;
+            b.ID = id[k]; b.Mass = mass[k];
+            b.Radius = cfg.collisions ? radius[k] : id[k] < radius_by_id.size() ? radius_by_id[id[k]] : 2.0;
             b.X = pos[3 * k]; b.Y = pos[3 * k + 1]; b.Z = pos[3 * k + 2];
             b.Vx = vel[3 * k]; b.Vy = vel[3 * k + 1]; b.Vz = vel[3 * k + 2];
         }

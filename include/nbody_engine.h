@@ -48,7 +48,8 @@ typedef struct {
     double bound_center[3];
     double bound_width;     /* edge of the cubic simulation bound; bodies outside are removed in tree mode */
     int device;             /* HIP device ordinal */
-    int reserved;
+    int collisions;         /* 0 = the `-nocollision` run (main.go:24); 1 = bodies that touch merge (tree mode:
+                               tree.go:245-281 + main.go:151-167 + physics.go:153-162) */
 } nbe_config;
 
 typedef struct {
@@ -59,6 +60,8 @@ typedef struct {
                                    nbe_accel / nbe_step_timed / nbe_time_force_kernel (plain steps do not count) */
     uint64_t tree_nodes;        /* leaves + branching cells of the last build */
     uint64_t tree_cells;        /* branching cells of the last build */
+    uint64_t merges;            /* bodies absorbed by collisions since upload (physics.go:153-162) */
+    uint64_t collision_pairs;   /* pairs queued by the collision search of the last step (main.go:153-159) */
     float ms_sort, ms_build, ms_force, ms_total;   /* device time of the last timed step (nbe_step_timed) */
 } nbe_stats_t;
 
@@ -74,7 +77,8 @@ typedef struct {
 } nbe_device_state_t;
 
 /* Fills cfg with the reference's constants: tree off, fp32, G = 6.67408e-11 (physics.go:132),
- * theta = 1 (main.go:73), dt = 3600 (main.go:28), eps = 0, bound centre 0 width 2^16 (main.go:74-76). */
+ * theta = 1 (main.go:73), dt = 3600 (main.go:28), eps = 0, bound centre 0 width 2^16 (main.go:74-76);
+ * collisions off (the reference's default is on, main.go:24: set cfg.collisions = 1 for that). */
 int nbe_default_config(nbe_config *cfg);
 
 int nbe_create(const nbe_config *cfg, nbe_engine **out);
@@ -89,6 +93,12 @@ const char *nbe_last_error(void);
 int nbe_upload(nbe_engine *e, size_t n, const double *pos_xyz, const double *vel_xyz, const double *mass,
                const uint64_t *id);
 
+/* Body radii (physics.go:94), used only by collisions.  nbe_upload gives every body the reference's
+ * defaultRadius 2 (physics.go:20); nbe_set_radius replaces them (n values in upload order) and needs an engine
+ * created with collisions on.  nbe_get_radius returns the radii of the live bodies in the order of nbe_download. */
+int nbe_set_radius(nbe_engine *e, const double *radius);
+int nbe_get_radius(nbe_engine *e, double *radius, size_t *n_alive);
+
 /* The copy of live bodies taken per frame at main.go:90-101.  Bodies removed by the tree bound check
  * (tree.go:290-292) are left out, as the nil skip at main.go:91-95 does; survivors keep upload order.
  * Any output pointer may be NULL.  *n_alive receives the number of bodies written. */
@@ -99,7 +109,11 @@ int nbe_download(nbe_engine *e, double *pos_xyz, double *vel_xyz, double *mass, 
 int nbe_accel(nbe_engine *e, double *acc_xyz, uint8_t *alive_out);
 
 /* nsteps iterations of main.go:104-178: force pass, then v += f/m*dt; x += v*dt (physics.go:101-115)
- * fused into the force kernel's epilogue.  Asynchronous on the engine's stream. */
+ * fused into the force kernel's epilogue.  Asynchronous on the engine's stream.
+ * With collisions on (tree mode) a step is: force pass, collision search of every live body through the tree in
+ * upload order (tree.go:245-281, reproducing its pruning rules as written), the queued pairs merged one after
+ * the other in queue order (main.go:160-166, physics.go:153-162), then the update; an absorbed body leaves the
+ * simulation like one that left the bound.  Such a step reads the queue length back and so synchronises. */
 int nbe_step(nbe_engine *e, int nsteps);
 
 /* One step bracketed by device events; fills stats->ms_* (synchronises). */
@@ -138,14 +152,17 @@ int nbe_set_stream(nbe_engine *e, void *hip_stream);
  * The reference hands a copy of the live bodies to its output workers before every step through a channel of
  * capacity 32 (main.go:50-61, 90-101).  Here the copy leaves the GPU on a side stream into a ring of pinned host
  * buffers while the next step computes, and a library thread delivers it:
- *   cb(user, frame, n_alive, xyzm, ids)   xyzm = n_alive x (x, y, z, mass) as fp32 (the record the reference's own
- *                                         frame store keeps, gob.go:54-61, minus the constant radius), ids = body IDs;
- *                                         both valid only during the call; bodies come in device order.
+ *   cb(user, frame, n_alive, xyzm, radius, ids)
+ *                                         xyzm = n_alive x (x, y, z, mass) as fp32 and radius = n_alive x fp32 (the
+ *                                         record the reference's own frame store keeps, gob.go:54-61; radius is NULL
+ *                                         when collisions are off: radii are then whatever the host uploaded),
+ *                                         ids = body IDs; all valid only during the call; bodies come in device order.
  * `every` = steps between frames (the reference's iterPerFrame, main.go:29); frame k is the state before step
  * k*every since the call, numbered from `first_frame` (startFrame, main.go:41-47).  `slots` buffers are in flight at
  * most (the channel capacity); nbe_step blocks when all are waiting for the callback, as the channel send would.
  * nbe_frame_stream_end delivers what is pending and stops the thread; nbe_destroy and nbe_upload imply it. */
-typedef void (*nbe_frame_cb)(void *user, int frame, size_t n_alive, const float *xyzm, const uint64_t *ids);
+typedef void (*nbe_frame_cb)(void *user, int frame, size_t n_alive, const float *xyzm, const float *radius,
+                             const uint64_t *ids);
 int nbe_frame_stream_begin(nbe_engine *e, int every, int slots, int first_frame, nbe_frame_cb cb, void *user);
 int nbe_frame_stream_end(nbe_engine *e);
 

@@ -45,7 +45,8 @@ static int use_device(nbe_engine* e)
 static int free_state(nbe_engine* e)
 {
     void** ptrs[] = {&e->posm[0], &e->posm[1], &e->vel[0], &e->vel[1], (void**)&e->mirror[0], (void**)&e->mirror[1],
-                     (void**)&e->orig[0], (void**)&e->orig[1], &e->acc, &e->partial};
+                     (void**)&e->orig[0], (void**)&e->orig[1], &e->acc, &e->partial, (void**)&e->radius[0],
+                     (void**)&e->radius[1]};
     for (void** p : ptrs)
         if (*p) { NBE_HIP(hipFree(*p)); *p = nullptr; }
     e->partial_len = 0;
@@ -62,6 +63,11 @@ extern "C" int nbe_create(const nbe_config* cfg, nbe_engine** out)
     if (cfg->mode != NBE_MODE_DIRECT && cfg->mode != NBE_MODE_TREE) { nbe_set_error("bad mode %d", cfg->mode); return NBE_E_INVALID; }
     if (cfg->precision < NBE_PREC_F32 || cfg->precision > NBE_PREC_F64) { nbe_set_error("bad precision %d", cfg->precision); return NBE_E_INVALID; }
     if (!(cfg->bound_width > 0) || !(cfg->theta >= 0) || !(cfg->eps >= 0)) { nbe_set_error("bound_width must be > 0, theta and eps >= 0"); return NBE_E_INVALID; }
+    if (cfg->collisions != 0 && cfg->collisions != 1) { nbe_set_error("collisions must be 0 or 1"); return NBE_E_INVALID; }
+    if (cfg->collisions && cfg->mode != NBE_MODE_TREE) {
+        nbe_set_error("collisions are implemented for tree mode only (main.go:151-167); run the direct sum with collisions = 0");
+        return NBE_E_UNSUPPORTED;
+    }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
         nbe_set_error("no HIP device available (this library has no CPU path)");
@@ -94,6 +100,7 @@ extern "C" void nbe_destroy(nbe_engine* e)
     (void)frame_stream_stop(e);
     (void)hipStreamSynchronize(e->stream);
     (void)free_state(e);
+    (void)collide_workspace_free(e);
     TreeWork& w = e->tw;
     void* ptrs[] = {w.keys[0], w.keys[1], w.sidx[0], w.sidx[1], w.block_hist, w.scan_tmp, w.bt_first, w.bt_last, w.bt_parent,
                     w.bt_level, w.lvlmask, w.cellcnt, w.nodes, w.node_level, w.node_sum, w.counters, w.d_interactions,
@@ -139,6 +146,10 @@ extern "C" int nbe_upload(nbe_engine* e, size_t n, const double* pos, const doub
         if (e->cfg.precision == NBE_PREC_MIXED) NBE_HIP(hipMalloc((void**)&e->mirror[b], cap * sizeof(float4)));
     }
     NBE_HIP(hipMalloc(&e->acc, cap * e->elem));
+    if (e->cfg.collisions) {
+        NBE_HIP(hipMalloc((void**)&e->radius[0], cap * sizeof(double)));
+        NBE_HIP(hipMalloc((void**)&e->radius[1], cap * sizeof(double)));
+    }
     e->ids = new (std::nothrow) uint64_t[cap];
     if (!e->ids) { nbe_set_error("out of host memory"); return NBE_E_NOMEM; }
     for (size_t i = 0; i < n; i++) e->ids[i] = id ? id[i] : (uint64_t)i;
@@ -173,23 +184,67 @@ extern "C" int nbe_upload(nbe_engine* e, size_t n, const double* pos, const doub
     NBE_HIP(hipMemcpy(e->orig[0], ident.data(), n * 4, hipMemcpyHostToDevice));
     NBE_HIP(hipMemcpy(e->orig[1], ident.data(), n * 4, hipMemcpyHostToDevice));
     if (e->cfg.mode == NBE_MODE_TREE) NBE_TRY(tree_workspace_reserve(e));
+    if (e->cfg.collisions) {
+        NBE_TRY(collide_workspace_reserve(e));
+        NBE_TRY(collide_fill_radius(e, e->radius[0], 2.0));      // physics.go:20 defaultRadius
+        NBE_HIP(hipMemsetAsync(e->tw.counters, 0, 16 * sizeof(int), e->stream));
+        NBE_HIP(hipMemsetAsync(e->cw.dead, 0, n, e->stream));
+    }
     return NBE_OK;
 }
 
-// Number of live bodies: n until a tree build has removed some (device order keeps them at the tail).
-static int read_counts(nbe_engine* e, size_t* n_alive)
+// Device slots [0, *slots) held the live bodies at the last build (n until a build has removed some; device
+// order keeps the removed ones at the tail).  Collisions absorb bodies between builds: those are flagged in
+// e->cw.dead and counted out of stats.n_alive.
+static int read_counts(nbe_engine* e, size_t* slots)
 {
+    size_t* n_alive = slots;
+    size_t absorbed = 0;
     *n_alive = e->n;
     if (e->have_counts && e->n > 0) {
-        int c[4];
+        int c[8];
         NBE_HIP(hipMemcpyAsync(c, e->tw.counters, sizeof(c), hipMemcpyDeviceToHost, e->stream));
         NBE_HIP(hipStreamSynchronize(e->stream));
         *n_alive = (size_t)c[0];
+        absorbed = (size_t)c[3];
         e->stats.tree_nodes = (uint64_t)c[1];
         e->stats.tree_cells = (uint64_t)c[2];
+        e->stats.merges = (uint64_t)c[6];
     }
-    e->host_nalive = *n_alive;
-    e->stats.n_alive = *n_alive;
+    e->host_nalive = *n_alive - absorbed;
+    e->stats.n_alive = *n_alive - absorbed;
+    return NBE_OK;
+}
+
+// Host copy of the absorbed flags of the first `slots` device slots (all zero when collisions are off).
+static int read_dead(nbe_engine* e, size_t slots, std::vector<uint8_t>* dead)
+{
+    dead->assign(slots, 0);
+    if (e->cfg.collisions && e->have_counts && slots > 0) {
+        NBE_HIP(hipMemcpyAsync(dead->data(), e->cw.dead, slots, hipMemcpyDeviceToHost, e->stream));
+        NBE_HIP(hipStreamSynchronize(e->stream));
+    }
+    return NBE_OK;
+}
+
+// upload index -> device slot of every live body (0xffffffff for removed ones).
+static int live_slots(nbe_engine* e, std::vector<uint32_t>* slot_of, size_t* n_alive)
+{
+    const size_t n = e->n;
+    size_t slots = 0;
+    NBE_TRY(read_counts(e, &slots));
+    std::vector<uint8_t> dead;
+    NBE_TRY(read_dead(e, slots, &dead));
+    std::vector<uint32_t> horig(n);
+    if (n > 0) {
+        NBE_HIP(hipMemcpyAsync(horig.data(), e->orig[e->orig_cur], n * 4, hipMemcpyDeviceToHost, e->stream));
+        NBE_HIP(hipStreamSynchronize(e->stream));
+    }
+    slot_of->assign(n, 0xffffffffu);
+    size_t k = 0;
+    for (size_t d = 0; d < slots; d++)
+        if (!dead[d]) { (*slot_of)[horig[d]] = (uint32_t)d; k++; }
+    *n_alive = k;
     return NBE_OK;
 }
 
@@ -199,12 +254,11 @@ extern "C" int nbe_download(nbe_engine* e, double* pos, double* vel, double* mas
     NBE_TRY(use_device(e));
     if (e->advance_pending) { nbe_set_error("nbe_download between nbe_shard_advance and nbe_shard_commit"); return NBE_E_INVALID; }
     const size_t n = e->n;
+    std::vector<uint32_t> slot_of;
     size_t na = 0;
-    NBE_TRY(read_counts(e, &na));
+    NBE_TRY(live_slots(e, &slot_of, &na));
     if (n_alive_out) *n_alive_out = na;
     if (n == 0) return NBE_OK;
-    std::vector<uint32_t> horig(n);
-    NBE_HIP(hipMemcpyAsync(horig.data(), e->orig[e->orig_cur], n * 4, hipMemcpyDeviceToHost, e->stream));
     std::vector<double> hp, hv;
     std::vector<float> fp, fv;
     if (e->state64) {
@@ -217,10 +271,7 @@ extern "C" int nbe_download(nbe_engine* e, double* pos, double* vel, double* mas
         NBE_HIP(hipMemcpyAsync(fv.data(), e->vel[e->cur], n * 16, hipMemcpyDeviceToHost, e->stream));
     }
     NBE_HIP(hipStreamSynchronize(e->stream));
-    // survivors (device index < na) in upload order
-    std::vector<uint32_t> slot_of(n, 0xffffffffu);   // upload index -> device index
-    for (size_t d = 0; d < na; d++) slot_of[horig[d]] = (uint32_t)d;
-    size_t k = 0;
+    size_t k = 0;                                  // survivors in upload order
     for (size_t u = 0; u < n; u++) {
         const uint32_t d = slot_of[u];
         if (d == 0xffffffffu) continue;
@@ -235,6 +286,45 @@ extern "C" int nbe_download(nbe_engine* e, double* pos, double* vel, double* mas
     return NBE_OK;
 }
 
+extern "C" int nbe_set_radius(nbe_engine* e, const double* radius)
+{
+    if (!e) { nbe_set_error("engine is NULL"); return NBE_E_INVALID; }
+    if (!e->cfg.collisions) { nbe_set_error("nbe_set_radius needs an engine created with collisions on"); return NBE_E_INVALID; }
+    if (e->n > 0 && !radius) { nbe_set_error("radius is NULL"); return NBE_E_INVALID; }
+    NBE_TRY(use_device(e));
+    const size_t n = e->n;
+    if (n == 0) return NBE_OK;
+    for (size_t u = 0; u < n; u++)
+        if (!(radius[u] >= 0.0)) { nbe_set_error("radius[%zu] is negative or NaN", u); return NBE_E_INVALID; }
+    std::vector<uint32_t> horig(n);
+    NBE_HIP(hipMemcpyAsync(horig.data(), e->orig[e->orig_cur], n * 4, hipMemcpyDeviceToHost, e->stream));
+    NBE_HIP(hipStreamSynchronize(e->stream));
+    std::vector<double> dev(n);
+    for (size_t d = 0; d < n; d++) dev[d] = radius[horig[d]];
+    NBE_HIP(hipMemcpy(e->radius[e->cur], dev.data(), n * sizeof(double), hipMemcpyHostToDevice));
+    return NBE_OK;
+}
+
+extern "C" int nbe_get_radius(nbe_engine* e, double* radius, size_t* n_alive_out)
+{
+    if (!e) { nbe_set_error("engine is NULL"); return NBE_E_INVALID; }
+    if (!e->cfg.collisions) { nbe_set_error("nbe_get_radius needs an engine created with collisions on"); return NBE_E_INVALID; }
+    NBE_TRY(use_device(e));
+    const size_t n = e->n;
+    std::vector<uint32_t> slot_of;
+    size_t na = 0;
+    NBE_TRY(live_slots(e, &slot_of, &na));
+    if (n_alive_out) *n_alive_out = na;
+    if (n == 0 || !radius) return NBE_OK;
+    std::vector<double> dev(n);
+    NBE_HIP(hipMemcpyAsync(dev.data(), e->radius[e->cur], n * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    NBE_HIP(hipStreamSynchronize(e->stream));
+    size_t k = 0;
+    for (size_t u = 0; u < n; u++)
+        if (slot_of[u] != 0xffffffffu) radius[k++] = dev[slot_of[u]];
+    return NBE_OK;
+}
+
 static int force_pass(nbe_engine* e, uint64_t t0, uint64_t t1, bool fused, bool count = false)
 {
     if (fused) NBE_TRY(frame_stream_guard_write(e, e->cur ^ 1));
@@ -245,6 +335,7 @@ static int force_pass(nbe_engine* e, uint64_t t0, uint64_t t1, bool fused, bool 
 extern "C" int nbe_shard_prepare(nbe_engine* e)
 {
     if (!e) { nbe_set_error("engine is NULL"); return NBE_E_INVALID; }
+    if (e->cfg.collisions) { nbe_set_error("sharded stepping does not support collisions; use nbe_step"); return NBE_E_UNSUPPORTED; }
     NBE_TRY(use_device(e));
     if (e->advance_pending) { nbe_set_error("nbe_shard_prepare before nbe_shard_commit"); return NBE_E_INVALID; }
     if (!e->prepared) NBE_TRY(frame_stream_before_step(e));
@@ -256,6 +347,7 @@ extern "C" int nbe_shard_prepare(nbe_engine* e)
 extern "C" int nbe_shard_advance(nbe_engine* e)
 {
     if (!e) { nbe_set_error("engine is NULL"); return NBE_E_INVALID; }
+    if (e->cfg.collisions) { nbe_set_error("sharded stepping does not support collisions; use nbe_step"); return NBE_E_UNSUPPORTED; }
     NBE_TRY(use_device(e));
     if (!e->prepared) { nbe_set_error("nbe_shard_advance without nbe_shard_prepare"); return NBE_E_INVALID; }
     if (e->advance_pending) { nbe_set_error("nbe_shard_advance called twice"); return NBE_E_INVALID; }
@@ -337,7 +429,13 @@ static int step_once_full(nbe_engine* e)
         if (e->cfg.mode == NBE_MODE_TREE) NBE_TRY(force_pass(e, 0, e->n, false, true));
         NBE_HIP(hipEventRecord(e->ev[4], e->stream));
     }
-    NBE_TRY(force_pass(e, 0, e->n, true));
+    if (e->cfg.collisions) {
+        // accelerations first (the collision merge needs them apart from the update), then search, merge, update
+        NBE_TRY(force_pass(e, 0, e->n, false));
+        NBE_TRY(collide_and_update(e));
+    } else {
+        NBE_TRY(force_pass(e, 0, e->n, true));
+    }
     if (e->timing) NBE_HIP(hipEventRecord(e->ev[3], e->stream));
     e->cur ^= 1;
     e->prepared = false;
@@ -434,9 +532,11 @@ extern "C" int nbe_accel(nbe_engine* e, double* acc_xyz, uint8_t* alive_out)
     NBE_TRY(fetch_interactions(e));
     size_t na;
     NBE_TRY(read_counts(e, &na));
+    std::vector<uint8_t> dead;
+    NBE_TRY(read_dead(e, na, &dead));
     for (size_t d = 0; d < n; d++) {
         const size_t u = horig[d];
-        const bool live = d < na;
+        const bool live = d < na && !dead[d];
         for (int c = 0; c < 3; c++)
             acc_xyz[3 * u + c] = live ? (e->state64 ? ha[4 * d + c] : (double)fa[4 * d + c]) : 0.0;
         if (alive_out) alive_out[u] = live ? 1 : 0;

@@ -76,10 +76,37 @@ struct TreeWork {
     unsigned long long* d_interactions = nullptr;
 };
 
+// ---- collisions (tree mode) ------------------------------------------------------------------------------
+// Geometry of the pre-order nodes for the collision search, one record per node of the walk's node array
+// (same index).  The cell of a node is the depth-`level` cell that contains the Morton key `key`; a one-body
+// leaf lives in the depth plevel+1 cell (the reference's leaf is the direct child of the branching cell above it).
+struct CNode {
+    uint64_t key;       // Morton key of the node's first body
+    int body;           // sorted index of a leaf's body, -1 for a branching cell
+    int skip;           // first pre-order index after the subtree
+    uint8_t level;      // depth of the node's cell (leaf: plevel + 1; 22 for a leaf of a depth-21 bucket)
+    uint8_t plevel;     // depth of the branching cell above, 255 for the root
+    uint8_t pmask;      // which octants of that cell hold bodies (bit o = child o exists, tree.go:266)
+    uint8_t pad0;
+    uint32_t pad1;
+};
+static_assert(sizeof(CNode) == 24, "CNode must be 24 bytes");
+
+struct CollWork {
+    size_t cap = 0;                 // bodies the buffers are sized for
+    CNode* cnodes = nullptr;        // 2*cap + 2 records
+    uint32_t* count = nullptr;      // per upload index: pairs queued by that body
+    uint32_t* offset = nullptr;     // exclusive scan of count, cap + 1 entries
+    int2* pairs = nullptr;          // queue: (searching body, resident body) as sorted indices
+    size_t pairs_cap = 0;
+    uint8_t* dead = nullptr;        // per device slot: absorbed since the last sort
+};
+
 // Ring of pinned host buffers that carries frames from the GPU to a delivery thread.
 struct FrameSlot {
     float* xyzm = nullptr;        // pinned, n x 4 floats
     uint32_t* orig = nullptr;     // pinned, n x u32 (device order -> upload index)
+    float* radius = nullptr;      // pinned, n floats (collisions on)
     int* n_alive = nullptr;       // pinned scalar
     int* d_n_alive = nullptr;     // device snapshot of the live count, taken on the compute stream
     hipEvent_t done = nullptr;    // copy finished (side stream)
@@ -98,6 +125,7 @@ struct FrameStream {
     hipEvent_t copy_done[2] = {nullptr, nullptr};   // per state buffer: the last copy that read it has finished
     bool copy_pending[2] = {false, false};
     float4* staging = nullptr;    // device: fp32 copy of an fp64 state
+    float* radius_staging = nullptr;   // device: fp32 copy of the radii (collisions on)
     std::vector<FrameSlot> slots;
     std::deque<int> queue;        // slots waiting for delivery, in frame order
     std::mutex mu;
@@ -117,6 +145,8 @@ struct nbe_engine {
     void* vel[2] = {nullptr, nullptr};
     float4* mirror[2] = {nullptr, nullptr};   // MIXED: fp32 copy of posm used by the force kernels
     uint32_t* orig[2] = {nullptr, nullptr};   // device order -> upload index; flips only when the state is sorted
+    double* radius[2] = {nullptr, nullptr};   // collisions on: body radii, indexed like posm (follows `cur`)
+    CollWork cw;
     int orig_cur = 0;
     int cur = 0;
     bool timing = false;            // record phase events during the next step
@@ -147,6 +177,12 @@ int tree_workspace_reserve(nbe_engine* e);
 int tree_sort_and_build(nbe_engine* e);         // sorts cur -> cur^1, flips e->cur, builds the tree
 // tree_walk.hip
 int tree_forces(nbe_engine* e, int src_buf, uint64_t t0, uint64_t t1, bool fused, bool count, int dst_buf);
+// collide.hip
+int collide_workspace_reserve(nbe_engine* e);
+int collide_workspace_free(nbe_engine* e);
+int collide_fill_radius(nbe_engine* e, double* dst, double value);
+int collide_emit_nodes(nbe_engine* e);          // after the build: geometry records for the collision search
+int collide_and_update(nbe_engine* e);          // search + merge + update of the state in e->cur into e->cur^1
 // energy.hip
 int energy_compute(nbe_engine* e, double* ke, double* pe, double mom[3]);
 // frames.hip

@@ -11,6 +11,12 @@ __global__ __launch_bounds__(256) void narrow_state_kernel(const double4* __rest
     out[i] = make_float4((float)p.x, (float)p.y, (float)p.z, (float)p.w);
 }
 
+__global__ __launch_bounds__(256) void narrow_radius_kernel(const double* __restrict__ radius, float* __restrict__ out, int n)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = (float)radius[i];
+}
+
 static void delivery_loop(nbe_engine* e)
 {
     FrameStream& fs = e->fs;
@@ -29,9 +35,28 @@ static void delivery_loop(nbe_engine* e)
         const int na_raw = *s.n_alive;               // -1: no tree build has removed anything yet
         size_t na = na_raw < 0 ? e->n : (size_t)na_raw;
         if (na > e->n) na = e->n;
+        if (e->cfg.collisions) {
+            // bodies absorbed by a collision since the last build are parked outside the bound without mass:
+            // leave them out, as the nil check at main.go:91-95 does
+            const double W = e->cfg.bound_width;
+            const float px = (float)(e->cfg.bound_center[0] + 1.5 * W), py = (float)(e->cfg.bound_center[1] + 1.5 * W),
+                        pz = (float)(e->cfg.bound_center[2] + 1.5 * W);
+            size_t k = 0;
+            for (size_t d = 0; d < na; d++) {
+                const float* r = s.xyzm + 4 * d;
+                if (r[3] == 0.0f && r[0] == px && r[1] == py && r[2] == pz) continue;
+                if (k != d) {
+                    for (int c = 0; c < 4; c++) s.xyzm[4 * k + c] = r[c];
+                    s.radius[k] = s.radius[d];
+                    s.orig[k] = s.orig[d];
+                }
+                k++;
+            }
+            na = k;
+        }
         fs.ids_scratch.resize(na);
         for (size_t d = 0; d < na; d++) fs.ids_scratch[d] = e->ids[s.orig[d]];
-        fs.cb(fs.user, s.frame, na, s.xyzm, fs.ids_scratch.data());
+        fs.cb(fs.user, s.frame, na, s.xyzm, e->cfg.collisions ? s.radius : nullptr, fs.ids_scratch.data());
         {
             std::lock_guard<std::mutex> lk(fs.mu);
             s.busy = false;
@@ -57,10 +82,12 @@ extern "C" int nbe_frame_stream_begin(nbe_engine* e, int every, int slots, int f
     NBE_HIP(hipEventCreateWithFlags(&fs.copy_done[0], hipEventDisableTiming));
     NBE_HIP(hipEventCreateWithFlags(&fs.copy_done[1], hipEventDisableTiming));
     if (e->state64) NBE_HIP(hipMalloc((void**)&fs.staging, cap * sizeof(float4)));
+    if (e->cfg.collisions) NBE_HIP(hipMalloc((void**)&fs.radius_staging, cap * sizeof(float)));
     fs.slots.assign((size_t)slots, FrameSlot());
     for (FrameSlot& s : fs.slots) {
         NBE_HIP(hipHostMalloc((void**)&s.xyzm, cap * 4 * sizeof(float), hipHostMallocDefault));
         NBE_HIP(hipHostMalloc((void**)&s.orig, cap * sizeof(uint32_t), hipHostMallocDefault));
+        if (e->cfg.collisions) NBE_HIP(hipHostMalloc((void**)&s.radius, cap * sizeof(float), hipHostMallocDefault));
         NBE_HIP(hipHostMalloc((void**)&s.n_alive, sizeof(int), hipHostMallocDefault));
         NBE_HIP(hipMalloc((void**)&s.d_n_alive, sizeof(int)));
         NBE_HIP(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
@@ -118,6 +145,13 @@ int frame_stream_before_step(nbe_engine* e)
     }
     NBE_HIP(hipMemcpyAsync(s.xyzm, src, n * sizeof(float4), hipMemcpyDeviceToHost, fs.side));
     NBE_HIP(hipMemcpyAsync(s.orig, e->orig[e->orig_cur], n * sizeof(uint32_t), hipMemcpyDeviceToHost, fs.side));
+    if (e->cfg.collisions) {
+        // the radii live beside the state buffer and are rewritten together with it, so the same guard covers them
+        hipLaunchKernelGGL(narrow_radius_kernel, dim3(cdiv(n, 256)), dim3(256), 0, fs.side, (const double*)e->radius[e->cur],
+                           fs.radius_staging, (int)n);
+        NBE_HIP(hipGetLastError());
+        NBE_HIP(hipMemcpyAsync(s.radius, fs.radius_staging, n * sizeof(float), hipMemcpyDeviceToHost, fs.side));
+    }
     if (e->have_counts) NBE_HIP(hipMemcpyAsync(s.n_alive, s.d_n_alive, sizeof(int), hipMemcpyDeviceToHost, fs.side));
     else *s.n_alive = -1;
     NBE_HIP(hipEventRecord(s.done, fs.side));
@@ -146,12 +180,14 @@ int frame_stream_stop(nbe_engine* e)
     for (FrameSlot& s : fs.slots) {
         if (s.xyzm) (void)hipHostFree(s.xyzm);
         if (s.orig) (void)hipHostFree(s.orig);
+        if (s.radius) (void)hipHostFree(s.radius);
         if (s.n_alive) (void)hipHostFree(s.n_alive);
         if (s.d_n_alive) (void)hipFree(s.d_n_alive);
         if (s.done) (void)hipEventDestroy(s.done);
     }
     fs.slots.clear();
     if (fs.staging) { (void)hipFree(fs.staging); fs.staging = nullptr; }
+    if (fs.radius_staging) { (void)hipFree(fs.radius_staging); fs.radius_staging = nullptr; }
     if (fs.state_ready) { (void)hipEventDestroy(fs.state_ready); fs.state_ready = nullptr; }
     for (int b = 0; b < 2; b++)
         if (fs.copy_done[b]) { (void)hipEventDestroy(fs.copy_done[b]); fs.copy_done[b] = nullptr; }

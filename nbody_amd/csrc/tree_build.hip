@@ -15,6 +15,7 @@
 // one depth-21 cell (the reference would recurse without bound).  The centre of mass is the mass-weighted
 // mean, not the running update of tree.go:189-193.
 #include "engine_internal.h"
+#include "tree_keys.h"
 
 #define SORT_KPT 8                     // keys per thread
 #define SORT_TILE (256 * SORT_KPT)     // keys per workgroup
@@ -129,19 +130,6 @@ static int device_exclusive_scan(nbe_engine* e, const uint32_t* in, uint32_t* ou
 }
 
 // ---- Morton keys ------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint64_t spread3(uint32_t v)   // 21 bits -> every third bit of 63
-{
-    uint64_t x = v & 0x1fffffull;
-    x = (x | x << 32) & 0x1f00000000ffffull;
-    x = (x | x << 16) & 0x1f0000ff0000ffull;
-    x = (x | x << 8) & 0x100f00f00f00f00full;
-    x = (x | x << 4) & 0x10c30c30c30c30c3ull;
-    x = (x | x << 2) & 0x1249249249249249ull;
-    return x;
-}
-
-#define KEY_DEAD 0xffffffffffffffffull
-
 // Index q in [0, 2^21) of the depth-21 cell with lo + q*cell <= x < lo + (q+1)*cell.  x - lo may round
 // across a cell boundary, so the estimate is corrected against the boundaries themselves, which are exact
 // for a power-of-two bound: the result then equals the chain of sign tests of octantBits (tree.go:128-132).
@@ -296,9 +284,10 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const uint64_t* __re
 template <typename S4>
 __global__ __launch_bounds__(256) void permute_kernel(const uint32_t* __restrict__ idx, int n, const S4* __restrict__ pos_in,
                                                       const S4* __restrict__ vel_in, const uint32_t* __restrict__ orig_in,
-                                                      const float4* __restrict__ mirror_in, S4* __restrict__ pos_out,
-                                                      S4* __restrict__ vel_out, uint32_t* __restrict__ orig_out,
-                                                      float4* __restrict__ mirror_out)
+                                                      const float4* __restrict__ mirror_in, const double* __restrict__ radius_in,
+                                                      S4* __restrict__ pos_out, S4* __restrict__ vel_out,
+                                                      uint32_t* __restrict__ orig_out, float4* __restrict__ mirror_out,
+                                                      double* __restrict__ radius_out)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
@@ -307,21 +296,10 @@ __global__ __launch_bounds__(256) void permute_kernel(const uint32_t* __restrict
     vel_out[i] = vel_in[j];
     orig_out[i] = orig_in[j];
     if (mirror_in) mirror_out[i] = mirror_in[j];
+    if (radius_in) radius_out[i] = radius_in[j];
 }
 
 // ---- binary radix tree over the sorted keys ----------------------------------------------------------------
-// delta(i, j): length of the common prefix of keys i and j (keys occupy the low 63 bits), with the index as
-// tie-break for equal keys; -1 outside [0, na).
-__device__ __forceinline__ int key_delta(const uint64_t* __restrict__ keys, int na, int i, uint64_t ki, int j)
-{
-    if (j < 0 || j >= na) return -1;
-    const uint64_t kj = keys[j];
-    if (ki != kj) return __clzll((long long)(ki ^ kj)) - 1;
-    return 63 + __clz(i ^ j);
-}
-
-__device__ __forceinline__ int delta_level(int d) { int l = d / 3; return l > 21 ? 21 : l; }
-
 __global__ __launch_bounds__(256) void radix_tree_kernel(const uint64_t* __restrict__ keys, const int* __restrict__ counters,
                                                          int* __restrict__ bt_first, int* __restrict__ bt_last,
                                                          int* __restrict__ bt_parent, uint8_t* __restrict__ bt_level)
@@ -667,7 +645,8 @@ static int sort_and_build_t(nbe_engine* e)
     NBE_TRY(frame_stream_guard_write(e, nxt));
     hipLaunchKernelGGL((permute_kernel<S4>), dim3(nb), dim3(256), 0, e->stream, w.sidx[0], n, (const S4*)e->posm[cur],
                        (const S4*)e->vel[cur], e->orig[e->orig_cur], mixed ? e->mirror[cur] : (const float4*)nullptr,
-                       (S4*)e->posm[nxt], (S4*)e->vel[nxt], e->orig[e->orig_cur ^ 1], mixed ? e->mirror[nxt] : (float4*)nullptr);
+                       (const double*)e->radius[cur], (S4*)e->posm[nxt], (S4*)e->vel[nxt], e->orig[e->orig_cur ^ 1],
+                       mixed ? e->mirror[nxt] : (float4*)nullptr, e->radius[nxt]);
     NBE_HIP(hipGetLastError());
     e->cur = nxt;
     e->orig_cur ^= 1;
@@ -702,8 +681,14 @@ static int sort_and_build_t(nbe_engine* e)
         }
         NBE_HIP(hipGetLastError());
     }
+    if (e->cfg.collisions) NBE_TRY(collide_emit_nodes(e));
     if (e->timing) NBE_HIP(hipEventRecord(e->ev[2], e->stream));
     return NBE_OK;
+}
+
+int device_scan_u32(nbe_engine* e, const uint32_t* in, uint32_t* out, size_t len)
+{
+    return device_exclusive_scan<false>(e, in, out, len);
 }
 
 // Sorts the current state by Morton key into the other buffer (which becomes current) and builds the tree

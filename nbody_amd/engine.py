@@ -19,20 +19,23 @@ _PRECS = {"f32": PREC_F32, "mixed": PREC_MIXED, "f64": PREC_F64}
 EXPORTS = ("nbe_default_config", "nbe_create", "nbe_destroy", "nbe_last_error", "nbe_upload", "nbe_download",
            "nbe_accel", "nbe_step", "nbe_step_timed", "nbe_sync", "nbe_stats", "nbe_energy", "nbe_set_shard",
            "nbe_shard_prepare", "nbe_shard_advance", "nbe_shard_commit", "nbe_device_state", "nbe_set_stream",
-           "nbe_time_force_kernel", "nbe_tree_nodes", "nbe_frame_stream_begin", "nbe_frame_stream_end")
+           "nbe_time_force_kernel", "nbe_tree_nodes", "nbe_frame_stream_begin", "nbe_frame_stream_end",
+           "nbe_set_radius", "nbe_get_radius")
 
-FRAME_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_size_t, C.POINTER(C.c_float), C.POINTER(C.c_uint64))
+FRAME_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_size_t, C.POINTER(C.c_float), C.POINTER(C.c_float),
+                       C.POINTER(C.c_uint64))
 
 
 class Config(C.Structure):
     _fields_ = [("mode", C.c_int), ("precision", C.c_int), ("G", C.c_double), ("theta", C.c_double),
                 ("dt", C.c_double), ("eps", C.c_double), ("bound_center", C.c_double * 3),
-                ("bound_width", C.c_double), ("device", C.c_int), ("reserved", C.c_int)]
+                ("bound_width", C.c_double), ("device", C.c_int), ("collisions", C.c_int)]
 
 
 class Stats(C.Structure):
     _fields_ = [("n", C.c_uint64), ("n_alive", C.c_uint64), ("steps", C.c_uint64), ("interactions", C.c_uint64),
-                ("tree_nodes", C.c_uint64), ("tree_cells", C.c_uint64), ("ms_sort", C.c_float),
+                ("tree_nodes", C.c_uint64), ("tree_cells", C.c_uint64), ("merges", C.c_uint64),
+                ("collision_pairs", C.c_uint64), ("ms_sort", C.c_float),
                 ("ms_build", C.c_float), ("ms_force", C.c_float), ("ms_total", C.c_float)]
 
 
@@ -89,6 +92,8 @@ def load_library():
     lib.nbe_tree_nodes.argtypes = [vp, dp, C.c_size_t, C.POINTER(C.c_size_t)]
     lib.nbe_frame_stream_begin.argtypes = [vp, C.c_int, C.c_int, C.c_int, FRAME_CB, vp]
     lib.nbe_frame_stream_end.argtypes = [vp]
+    lib.nbe_set_radius.argtypes = [vp, dp]
+    lib.nbe_get_radius.argtypes = [vp, dp, C.POINTER(C.c_size_t)]
     for name in EXPORTS:
         if name not in ("nbe_destroy", "nbe_last_error"):
             getattr(lib, name).restype = C.c_int
@@ -105,7 +110,7 @@ class Engine:
     step(), download the copy a frame would take (main.go:90-101)."""
 
     def __init__(self, mode="direct", precision="f32", theta=None, dt=None, eps=None, G=None,
-                 bound_center=None, bound_width=None, device=0):
+                 bound_center=None, bound_width=None, device=0, collisions=False):
         self._lib = load_library()
         cfg = Config()
         self._check(self._lib.nbe_default_config(C.byref(cfg)))
@@ -124,6 +129,7 @@ class Engine:
         if bound_width is not None:
             cfg.bound_width = float(bound_width)
         cfg.device = int(device)
+        cfg.collisions = int(bool(collisions))      # False = the reference's -nocollision run (main.go:24)
         self.cfg = cfg
         self._h = C.c_void_p()
         self._check(self._lib.nbe_create(C.byref(cfg), C.byref(self._h)))
@@ -177,6 +183,20 @@ class Engine:
         k = k.value
         return pos[:k], vel[:k], mass[:k], ids[:k]
 
+    def set_radius(self, radius):
+        """Body radii (physics.go:94) in upload order; collisions only.  Bodies start with radius 2 (physics.go:20)."""
+        radius = np.ascontiguousarray(radius, dtype=np.float64).reshape(-1)
+        if radius.shape[0] != self.n:
+            raise ValueError("radius has the wrong length")
+        self._check(self._lib.nbe_set_radius(self._h, _dp(radius)))
+
+    def get_radius(self):
+        """Radii of the live bodies, in the order of download()."""
+        radius = np.zeros(self.n)
+        k = C.c_size_t(0)
+        self._check(self._lib.nbe_get_radius(self._h, _dp(radius), C.byref(k)))
+        return radius[:k.value]
+
     # ---- force / step ----
     def accel(self):
         """Accelerations f/m of all uploaded bodies (upload order) and their alive flags."""
@@ -223,12 +243,16 @@ class Engine:
 
     # ---- frame streaming ----
     def frame_stream_begin(self, callback, every=1, slots=32, first_frame=0):
-        """callback(frame, xyzm[n_alive,4] float32, ids[n_alive] uint64) runs on a library thread for the state
-        before every `every`-th step; the arrays are copies the callback may keep."""
-        def tramp(_user, frame, n, xyzm, ids):
+        """callback(frame, xyzm[n_alive,4] float32, ids[n_alive] uint64, radius[n_alive] float32 or None) runs on a
+        library thread for the state before every `every`-th step; the arrays are copies the callback may keep.
+        radius is None unless collisions are on."""
+        def tramp(_user, frame, n, xyzm, radius, ids):
             a = np.ctypeslib.as_array(xyzm, shape=(n, 4)).copy() if n else np.zeros((0, 4), np.float32)
             i = np.ctypeslib.as_array(ids, shape=(n,)).copy() if n else np.zeros(0, np.uint64)
-            callback(frame, a, i)
+            r = None
+            if radius:
+                r = np.ctypeslib.as_array(radius, shape=(n,)).copy() if n else np.zeros(0, np.float32)
+            callback(frame, a, i, r)
         self._frame_cb = FRAME_CB(tramp)          # keep the thunk alive while streaming
         self._check(self._lib.nbe_frame_stream_begin(self._h, int(every), int(slots), int(first_frame), self._frame_cb, None))
 

@@ -79,6 +79,48 @@ static void direct_forces(orc_body *bodies, long n)
     }
 }
 
+/* physics.go:148-150 */
+static double inelastic_collision(double ma, double va, double mb, double vb)
+{
+    return (ma * va + mb * vb) / (ma + mb);
+}
+
+/* physics.go:153-162: b merges into a.  a->Mass is already the sum when the velocities are mixed, exactly
+ * as the reference writes it. */
+static void body_combine(orc_body *a, const orc_body *b)
+{
+    a->Mass = a->Mass + b->Mass;
+    a->Radius = cbrt(a->Radius * a->Radius * a->Radius + b->Radius * b->Radius * b->Radius);
+    a->Vx = inelastic_collision(a->Mass, a->Vx, b->Mass, b->Vx);
+    a->Vy = inelastic_collision(a->Mass, a->Vy, b->Mass, b->Vy);
+    a->Vz = inelastic_collision(a->Mass, a->Vz, b->Mass, b->Vz);
+    a->fx = a->fx + b->fx;
+    a->fy = a->fy + b->fy;
+    a->fz = a->fz + b->fz;
+}
+
+/* main.go:107-128 with collisions on: a pair that touches merges on the spot and the absorbed body is
+ * skipped from then on.  Returns the number of merges. */
+static long direct_forces_collide(orc_body *bodies, long n)
+{
+    long merges = 0;
+    for (long i = 0; i < n - 1; i++) {
+        if (!bodies[i].alive) continue;
+        for (long j = i + 1; j < n; j++) {
+            if (!bodies[j].alive) continue;
+            double r = body_dist(&bodies[i], &bodies[j]);
+            body_gravity(r, &bodies[i], &bodies[j]);
+            body_gravity(r, &bodies[j], &bodies[i]);
+            if (r <= bodies[i].Radius + bodies[j].Radius) {
+                body_combine(&bodies[i], &bodies[j]);
+                bodies[j].alive = 0;
+                merges++;
+            }
+        }
+    }
+    return merges;
+}
+
 /* ---------------------------------------------------------------- octree (tree.go) */
 
 typedef struct { double center[3], width[3]; } nodebound;   /* tree.go:41-43 */
@@ -96,6 +138,22 @@ static int bound_contains(const nodebound *n, const double p[3])
     return (n->center[0] - hw0 <= p[0] && p[0] < n->center[0] + hw0) &&
            (n->center[1] - hw1 <= p[1] && p[1] < n->center[1] + hw1) &&
            (n->center[2] - hw2 <= p[2] && p[2] < n->center[2] + hw2);
+}
+
+/* tree.go:75-79: the full width (not half) minus r is compared with the offset from the centre. */
+static int bound_contains_sphere(const nodebound *n, const double p[3], double r)
+{
+    double w0 = n->width[0] - r, w1 = n->width[1] - r, w2 = n->width[2] - r;
+    double d0 = p[0] - n->center[0], d1 = p[1] - n->center[1], d2 = p[2] - n->center[2];
+    return fabs(d0) <= w0 && fabs(d1) <= w1 && fabs(d2) <= w2;
+}
+
+/* tree.go:82-86: full width plus r, and one axis within reach is enough (the reference writes ||). */
+static int bound_intersect_sphere(const nodebound *n, const double p[3], double r)
+{
+    double w0 = n->width[0] + r, w1 = n->width[1] + r, w2 = n->width[2] + r;
+    double d0 = p[0] - n->center[0], d1 = p[1] - n->center[1], d2 = p[2] - n->center[2];
+    return fabs(d0) <= w0 || fabs(d1) <= w1 || fabs(d2) <= w2;
 }
 
 /* tree.go:101-110 (with scale :89-92 and translate :95-98) */
@@ -304,6 +362,67 @@ static long node_gravity(const orc_node *n, orc_body *bodies, long bi, double th
     return 1;
 }
 
+/* The queue of main.go:153: pairs (searching body, resident body of the leaf it touched). */
+typedef struct { long (*pair)[2]; long len, cap; } pairlist;
+
+static void pairlist_push(pairlist *l, long a, long b)
+{
+    if (l->len == l->cap) {
+        l->cap = l->cap ? l->cap * 2 : 64;
+        l->pair = (long (*)[2])realloc(l->pair, sizeof(long[2]) * (size_t)l->cap);
+    }
+    l->pair[l->len][0] = a; l->pair[l->len][1] = b; l->len++;
+}
+
+/* tree.go:245-281.  A bucket of the depth-cap extension checks all of its leaves. */
+static void node_check_collision(const orc_node *n, const orc_body *bodies, long bi, pairlist *out)
+{
+    if (n->particle == bi) return;                                   /* tree.go:246-248 */
+    const orc_body *b = &bodies[bi];
+    double p[3] = { b->X, b->Y, b->Z };
+    if (!bound_intersect_sphere(&n->bounds, p, b->Radius)) return;
+    if (n->kind == KIND_EXTERNAL) {
+        if (n->particle >= 0 && bodies[n->particle].alive) {
+            double r = body_dist(&bodies[n->particle], b);
+            if (r <= bodies[n->particle].Radius + b->Radius) pairlist_push(out, bi, n->particle);
+        }
+        return;
+    }
+    if (n->bucket) {
+        for (long i = 0; i < n->nbucket; i++) node_check_collision(n->bucket[i], bodies, bi, out);
+        return;
+    }
+    unsigned oct = octant_bits(n->bounds.center, p);
+    if (n->children[oct] && bound_contains_sphere(&n->children[oct]->bounds, p, b->Radius)) {
+        node_check_collision(n->children[oct], bodies, bi, out);      /* tree.go:266-270 */
+    } else {
+        for (int i = 0; i < 8; i++)
+            if (n->children[i]) node_check_collision(n->children[i], bodies, bi, out);
+    }
+}
+
+/* main.go:152-167: every live body searches the tree in slice order, then the queue is worked off in order;
+ * a pair with a body that an earlier merge removed is dropped.  Returns the number of merges. */
+static long tree_collisions(const orc_node *root, orc_body *bodies, long n, long *queued)
+{
+    pairlist q = { NULL, 0, 0 };
+    for (long i = 0; i < n; i++) {
+        if (!bodies[i].alive) continue;
+        node_check_collision(root, bodies, i, &q);
+    }
+    long merges = 0;
+    for (long k = 0; k < q.len; k++) {
+        orc_body *a = &bodies[q.pair[k][0]], *b = &bodies[q.pair[k][1]];
+        if (!a->alive || !b->alive) continue;
+        body_combine(a, b);
+        b->alive = 0;
+        merges++;
+    }
+    if (queued) *queued += q.len;
+    free(q.pair);
+    return merges;
+}
+
 typedef struct { const orc_node *root; orc_body *bodies; long lo, hi; double theta; long count; } walk_job;
 
 static void *walk_thread(void *arg)
@@ -321,13 +440,13 @@ static void *walk_thread(void *arg)
 /* main.go:133-149.  groups = 4 in the reference; groupsize = n/groups, so with drop_tail the last
  * n % groups bodies get no force, exactly as the slicing at main.go:147 leaves them out. */
 static long tree_forces(orc_tree *t, long n, const nodebound *simbound, double theta, int groups, int drop_tail,
-                        double *build_seconds, double *walk_seconds);
+                        double *build_seconds, double *walk_seconds, int collide, long *merges, long *queued);
 
 #include <time.h>
 static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
 
 static long tree_forces(orc_tree *t, long n, const nodebound *simbound, double theta, int groups, int drop_tail,
-                        double *build_seconds, double *walk_seconds)
+                        double *build_seconds, double *walk_seconds, int collide, long *merges, long *queued)
 {
     double t0 = now_s();
     orc_node *root = maketree(t, n, simbound);
@@ -350,6 +469,7 @@ static long tree_forces(orc_tree *t, long n, const nodebound *simbound, double t
     long total = 0;
     for (int g = 0; g < groups; g++) total += jobs[g].count;
     double t2 = now_s();
+    if (collide) *merges += tree_collisions(root, t->bodies, n, queued);
     if (build_seconds) *build_seconds += t1 - t0;
     if (walk_seconds) *walk_seconds += t2 - t1;
     return total;
@@ -375,8 +495,16 @@ typedef struct {
     double root_mass, root_com[3];
     double build_seconds, walk_seconds, update_seconds;
     int overflow;
+    long merges;         /* bodies absorbed by collisions (physics.go:153-162) */
+    long queued;         /* tree mode: pairs queued by checkCollision (main.go:153-159) */
 } orc_stats;
 
+static void load_bodies(orc_body *bs, long n, const double *mass, const double *pos, const double *vel,
+                        const unsigned char *alive);
+static void load_radius(orc_body *bs, long n, const double *radius)
+{
+    for (long i = 0; i < n; i++) bs[i].Radius = radius ? radius[i] : 2.0;   /* physics.go:20 defaultRadius */
+}
 static void load_bodies(orc_body *bs, long n, const double *mass, const double *pos, const double *vel,
                         const unsigned char *alive)
 {
@@ -390,11 +518,12 @@ static void load_bodies(orc_body *bs, long n, const double *mass, const double *
     }
 }
 
-static void forces_once(orc_body *bs, long n, const orc_params *p, orc_stats *st)
+static void forces_once(orc_body *bs, long n, const orc_params *p, orc_stats *st, int collide)
 {
     if (p->mode == 0) {
         double t0 = now_s();
-        direct_forces(bs, n);
+        if (collide) st->merges += direct_forces_collide(bs, n);
+        else direct_forces(bs, n);
         long live = 0;
         for (long i = 0; i < n; i++) live += bs[i].alive;
         st->interactions += live * (live - 1);
@@ -405,7 +534,7 @@ static void forces_once(orc_body *bs, long n, const orc_params *p, orc_stats *st
         nodebound sb;
         for (int k = 0; k < 3; k++) { sb.center[k] = p->bound_center[k]; sb.width[k] = p->bound_width; }
         st->interactions += tree_forces(&t, n, &sb, p->theta, p->groups, p->drop_tail,
-                                        &st->build_seconds, &st->walk_seconds);
+                                        &st->build_seconds, &st->walk_seconds, collide, &st->merges, &st->queued);
         st->nodes = t.nnodes;
         /* the root is the first node of the oldest arena block */
         arena_block *b = t.blocks; while (b->next) b = b->next;
@@ -424,7 +553,7 @@ int orc_forces(long n, const double *mass, const double *pos, unsigned char *ali
     orc_body *bs = (orc_body *)malloc(sizeof(orc_body) * (size_t)(n > 0 ? n : 1));
     orc_stats local; memset(&local, 0, sizeof(local));
     load_bodies(bs, n, mass, pos, NULL, alive);
-    if (n > 0) forces_once(bs, n, p, &local);
+    if (n > 0) forces_once(bs, n, p, &local, 0);
     for (long i = 0; i < n; i++) {
         force_out[3 * i] = bs[i].fx; force_out[3 * i + 1] = bs[i].fy; force_out[3 * i + 2] = bs[i].fz;
         if (alive) alive[i] = (unsigned char)bs[i].alive;
@@ -434,15 +563,17 @@ int orc_forces(long n, const double *mass, const double *pos, unsigned char *ali
     return 0;
 }
 
-/* Advance the state by nsteps iterations of main.go:104-178 (collisions off). */
-int orc_step(long n, const double *mass, double *pos, double *vel, unsigned char *alive, const orc_params *p,
-             int nsteps, orc_stats *st)
+/* Advance the state by nsteps iterations of main.go:104-178.  collide = 0 is the `-nocollision` run; with
+ * collide != 0 masses, radii and the live set change too (radius NULL = every body 2, physics.go:20). */
+int orc_step2(long n, double *mass, double *radius, double *pos, double *vel, unsigned char *alive,
+              const orc_params *p, int collide, int nsteps, orc_stats *st)
 {
     orc_body *bs = (orc_body *)malloc(sizeof(orc_body) * (size_t)(n > 0 ? n : 1));
     orc_stats local; memset(&local, 0, sizeof(local));
     load_bodies(bs, n, mass, pos, vel, alive);
+    load_radius(bs, n, radius);
     for (int s = 0; s < nsteps && n > 0; s++) {
-        forces_once(bs, n, p, &local);
+        forces_once(bs, n, p, &local, collide);
         double t0 = now_s();
         for (long i = 0; i < n; i++) {                 /* main.go:171-177 */
             if (!bs[i].alive) continue;
@@ -453,11 +584,45 @@ int orc_step(long n, const double *mass, double *pos, double *vel, unsigned char
     for (long i = 0; i < n; i++) {
         pos[3 * i] = bs[i].X; pos[3 * i + 1] = bs[i].Y; pos[3 * i + 2] = bs[i].Z;
         vel[3 * i] = bs[i].Vx; vel[3 * i + 1] = bs[i].Vy; vel[3 * i + 2] = bs[i].Vz;
+        if (collide) { mass[i] = bs[i].Mass; if (radius) radius[i] = bs[i].Radius; }
         if (alive) alive[i] = (unsigned char)bs[i].alive;
     }
     free(bs);
     if (st) *st = local;
     return 0;
+}
+
+int orc_step(long n, const double *mass, double *pos, double *vel, unsigned char *alive, const orc_params *p,
+             int nsteps, orc_stats *st)
+{
+    return orc_step2(n, (double *)mass, NULL, pos, vel, alive, p, 0, nsteps, st);
+}
+
+/* One collision search over the tree of the given state (no forces, no merging): the queue of
+ * main.go:153-159 as index pairs (searcher, resident).  Returns the queue length; at most cap pairs are written. */
+long orc_collision_queue(long n, const double *mass, const double *radius, const double *pos, unsigned char *alive,
+                         const orc_params *p, long *pairs_out, long cap)
+{
+    orc_body *bs = (orc_body *)malloc(sizeof(orc_body) * (size_t)(n > 0 ? n : 1));
+    load_bodies(bs, n, mass, pos, NULL, alive);
+    load_radius(bs, n, radius);
+    orc_tree t; memset(&t, 0, sizeof(t));
+    t.com_mode = p->com_mode; t.max_depth = p->max_depth; t.bodies = bs;
+    nodebound sb;
+    for (int k = 0; k < 3; k++) { sb.center[k] = p->bound_center[k]; sb.width[k] = p->bound_width; }
+    orc_node *root = maketree(&t, n, &sb);
+    pairlist q = { NULL, 0, 0 };
+    for (long i = 0; i < n; i++) {
+        if (!bs[i].alive) continue;
+        node_check_collision(root, bs, i, &q);
+    }
+    for (long k = 0; k < q.len && k < cap; k++) { pairs_out[2 * k] = q.pair[k][0]; pairs_out[2 * k + 1] = q.pair[k][1]; }
+    long len = q.len;
+    if (alive) for (long i = 0; i < n; i++) alive[i] = (unsigned char)bs[i].alive;
+    free(q.pair);
+    tree_free(&t);
+    free(bs);
+    return len;
 }
 
 /* Tree inspection for structure parity: pre-order dump (children in octant order 0..7) of every node

@@ -28,7 +28,7 @@ class Params(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("interactions", C.c_long), ("nodes", C.c_long), ("root_mass", C.c_double),
                 ("root_com", C.c_double * 3), ("build_seconds", C.c_double), ("walk_seconds", C.c_double),
-                ("update_seconds", C.c_double), ("overflow", C.c_int)]
+                ("update_seconds", C.c_double), ("overflow", C.c_int), ("merges", C.c_long), ("queued", C.c_long)]
 
 
 class NodeInfo(C.Structure):
@@ -57,6 +57,10 @@ def lib():
         up = C.POINTER(C.c_ubyte)
         _lib.orc_forces.argtypes = [C.c_long, dp, dp, up, C.POINTER(Params), dp, C.POINTER(Stats)]
         _lib.orc_step.argtypes = [C.c_long, dp, dp, dp, up, C.POINTER(Params), C.c_int, C.POINTER(Stats)]
+        lp = C.POINTER(C.c_long)
+        _lib.orc_step2.argtypes = [C.c_long, dp, dp, dp, dp, up, C.POINTER(Params), C.c_int, C.c_int, C.POINTER(Stats)]
+        _lib.orc_collision_queue.argtypes = [C.c_long, dp, dp, dp, up, C.POINTER(Params), lp, C.c_long]
+        _lib.orc_collision_queue.restype = C.c_long
         _lib.orc_tree_dump.argtypes = [C.c_long, dp, dp, up, C.POINTER(Params), C.POINTER(NodeInfo), C.c_long]
         _lib.orc_tree_dump.restype = C.c_long
         _lib.orc_energy.argtypes = [C.c_long, dp, dp, dp, up, C.c_double, dp, dp, dp]
@@ -118,6 +122,34 @@ def step(mass, pos, vel, nsteps=1, alive=None, **kw):
     st = Stats()
     lib().orc_step(n, _dp(mass), _dp(pos), _dp(vel), _up(alive), C.byref(p), int(nsteps), C.byref(st))
     return pos, vel, alive, st
+
+
+def step_collide(mass, radius, pos, vel, nsteps=1, alive=None, **kw):
+    """Advance nsteps iterations with collisions on (main.go:122-126 direct, :151-167 tree).
+    Returns (mass, radius, pos, vel, alive, Stats); inputs are not modified."""
+    n, mass, pos, vel, alive = _prep(mass, pos, vel, alive)
+    mass, pos, vel = mass.copy(), pos.copy(), vel.copy()
+    radius = np.full(n, 2.0) if radius is None else np.ascontiguousarray(radius, dtype=np.float64).copy()
+    p = make_params(**kw)
+    st = Stats()
+    lib().orc_step2(n, _dp(mass), _dp(radius), _dp(pos), _dp(vel), _up(alive), C.byref(p), 1, int(nsteps), C.byref(st))
+    return mass, radius, pos, vel, alive, st
+
+
+def collision_queue(mass, radius, pos, alive=None, **kw):
+    """The (searcher, resident) pairs checkCollision queues for this state, in queue order (main.go:153-159)."""
+    n, mass, pos, _, alive = _prep(mass, pos, None, alive)
+    radius = np.full(n, 2.0) if radius is None else np.ascontiguousarray(radius, dtype=np.float64)
+    p = make_params(mode="tree", **kw)
+    cap = 64
+    while True:
+        buf = np.zeros((cap, 2), dtype=np.int64)
+        a = alive.copy()
+        k = lib().orc_collision_queue(n, _dp(mass), _dp(radius), _dp(pos), _up(a), C.byref(p),
+                                      buf.ctypes.data_as(C.POINTER(C.c_long)), cap)
+        if k <= cap:
+            return buf[:k].copy(), a
+        cap = k
 
 
 def tree_dump(mass, pos, alive=None, **kw):

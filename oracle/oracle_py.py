@@ -62,6 +62,53 @@ def gravity(r, a, b):
     a.fz += dfz
 
 
+def inelastic_collision(ma, va, mb, vb):
+    """physics.go:148-150"""
+    return (ma * va + mb * vb) / (ma + mb)
+
+
+def _cbrt(x):
+    """math.Cbrt for x >= 0, correctly rounded from a Newton-polished power (C's cbrt agrees to the last bit on
+    the values the tests use; the tests compare radii with a one-ulp tolerance)."""
+    if x == 0.0:
+        return 0.0
+    y = x ** (1.0 / 3.0)
+    y = y - (y * y * y - x) / (3.0 * y * y)
+    return y
+
+
+def combine(a, b):
+    """physics.go:153-162: a.Mass is overwritten first and then used as `ma`."""
+    a.Mass = a.Mass + b.Mass
+    a.Radius = _cbrt(a.Radius * a.Radius * a.Radius + b.Radius * b.Radius * b.Radius)
+    a.Vx = inelastic_collision(a.Mass, a.Vx, b.Mass, b.Vx)
+    a.Vy = inelastic_collision(a.Mass, a.Vy, b.Mass, b.Vy)
+    a.Vz = inelastic_collision(a.Mass, a.Vz, b.Mass, b.Vz)
+    a.fx = a.fx + b.fx
+    a.fy = a.fy + b.fy
+    a.fz = a.fz + b.fz
+
+
+def direct_pass_collide(bodies):
+    """main.go:107-128 with collisions on; returns the number of merges."""
+    n = len(bodies)
+    merges = 0
+    for i in range(n - 1):
+        if bodies[i] is None:
+            continue
+        for j in range(i + 1, n):
+            if bodies[j] is None:
+                continue
+            r = dist(bodies[i], bodies[j])
+            gravity(r, bodies[i], bodies[j])
+            gravity(r, bodies[j], bodies[i])
+            if r <= bodies[i].Radius + bodies[j].Radius:
+                combine(bodies[i], bodies[j])
+                bodies[j] = None
+                merges += 1
+    return merges
+
+
 def direct_pass(bodies):
     """main.go:107-128 with -nocollision"""
     n = len(bodies)
@@ -103,6 +150,18 @@ class Bound:
         return ((c[0] - h[0] <= p[0] and p[0] < c[0] + h[0]) and
                 (c[1] - h[1] <= p[1] and p[1] < c[1] + h[1]) and
                 (c[2] - h[2] <= p[2] and p[2] < c[2] + h[2]))
+
+
+def contains_sphere(bound, p, r):
+    """tree.go:75-79"""
+    c, w = bound.center, bound.width
+    return (abs(p[0] - c[0]) <= w[0] - r) and (abs(p[1] - c[1]) <= w[1] - r) and (abs(p[2] - c[2]) <= w[2] - r)
+
+
+def intersect_sphere(bound, p, r):
+    """tree.go:82-86"""
+    c, w = bound.center, bound.width
+    return (abs(p[0] - c[0]) <= w[0] + r) or (abs(p[1] - c[1]) <= w[1] + r) or (abs(p[2] - c[2]) <= w[2] + r)
 
 
 def octant_bound(parent, oct_):
@@ -194,6 +253,47 @@ class Node:
         return 1
 
 
+def check_collision(node, bodies, bi, queue):
+    """tree.go:245-281"""
+    if node.particle is not None and node.particle == bi:
+        return
+    b = bodies[bi]
+    p = (b.X, b.Y, b.Z)
+    if not intersect_sphere(node.bounds, p, b.Radius):
+        return
+    if node.kind == EXTERNAL:
+        if node.particle is not None and bodies[node.particle] is not None:
+            o = bodies[node.particle]
+            if dist(o, b) <= o.Radius + b.Radius:
+                queue.append((bi, node.particle))
+        return
+    oct_ = octant_bits(node.bounds.center, p)
+    ch = node.children[oct_]
+    if ch is not None and contains_sphere(ch.bounds, p, b.Radius):
+        check_collision(ch, bodies, bi, queue)
+    else:
+        for c in node.children:
+            if c is not None:
+                check_collision(c, bodies, bi, queue)
+
+
+def tree_collisions(root, bodies):
+    """main.go:152-167; returns (queue, merges)."""
+    queue = []
+    for i in range(len(bodies)):
+        if bodies[i] is None:
+            continue
+        check_collision(root, bodies, i, queue)
+    merges = 0
+    for a, b in queue:
+        if bodies[a] is None or bodies[b] is None:
+            continue
+        combine(bodies[a], bodies[b])
+        bodies[b] = None
+        merges += 1
+    return queue, merges
+
+
 def maketree(bodies, simbound, true_com=False):
     """tree.go:284-295"""
     root = Node(simbound)
@@ -223,11 +323,15 @@ def tree_pass(bodies, theta=1.0, bound_center=(0.0, 0.0, 0.0), bound_width=65536
     return root, count
 
 
-def simulate(bodies, nsteps, tree=True, dt=3600.0, **kw):
-    """main.go:104-178 repeated nsteps times (collisions off)."""
+def simulate(bodies, nsteps, tree=True, dt=3600.0, collide=False, **kw):
+    """main.go:104-178 repeated nsteps times; collide=False is the -nocollision run."""
     for _ in range(nsteps):
         if tree:
-            tree_pass(bodies, **kw)
+            root, _ = tree_pass(bodies, **kw)
+            if collide:
+                tree_collisions(root, bodies)
+        elif collide:
+            direct_pass_collide(bodies)
         else:
             direct_pass(bodies)
         for b in bodies:

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_layouts_match_header_sizes():
     assert C.sizeof(E.Config) == 2 * 4 + 4 * 8 + 3 * 8 + 8 + 2 * 4
-    assert C.sizeof(E.Stats) == 6 * 8 + 4 * 4
+    assert C.sizeof(E.Stats) == 8 * 8 + 4 * 4
     assert C.sizeof(E.DeviceState) == 4 * 8 + 8 + 4 + 4
 
 
@@ -38,7 +38,7 @@ def test_default_config_holds_reference_constants():
     assert lib.nbe_default_config(C.byref(cfg)) == 0
     assert cfg.G == 6.67408e-11 and cfg.theta == 1.0 and cfg.dt == 3600.0 and cfg.eps == 0.0
     assert cfg.bound_width == 65536.0 and list(cfg.bound_center) == [0.0, 0.0, 0.0]
-    assert cfg.mode == E.MODE_DIRECT and cfg.precision == E.PREC_F32
+    assert cfg.mode == E.MODE_DIRECT and cfg.precision == E.PREC_F32 and cfg.collisions == 0
     assert lib.nbe_default_config(None) == -1
     assert b"NULL" in lib.nbe_last_error()
 
@@ -50,6 +50,13 @@ def test_create_rejects_bad_arguments():
     h = C.c_void_p()
     cfg.mode = 7
     assert lib.nbe_create(C.byref(cfg), C.byref(h)) == -1 and not h.value
+    cfg.mode = 0
+    cfg.collisions = 1      # collisions exist in tree mode only
+    assert lib.nbe_create(C.byref(cfg), C.byref(h)) == -4 and not h.value
+    assert b"tree mode" in lib.nbe_last_error()
+    cfg.collisions = 2
+    assert lib.nbe_create(C.byref(cfg), C.byref(h)) == -1 and not h.value
+    cfg.collisions = 0
     cfg.mode = 1
     cfg.precision = 9
     assert lib.nbe_create(C.byref(cfg), C.byref(h)) == -1

@@ -1,0 +1,219 @@
+"""Collisions on the GPU (tree mode) against the CPU restatement: the search of tree.go:245-281 with its pruning
+rules as written, the queue order of main.go:153-159, the serial merge of main.go:160-166 with combine
+(physics.go:153-162), then the update.  The oracle runs with the mass-weighted centre of mass, all bodies walked
+and the depth cap of 21, which are the engine's stated deviations on the force side."""
+import numpy as np
+import pytest
+
+from nbody_amd import Engine, EngineError
+from nbody_amd import physics
+from oracle import oracle as O
+from tests.util import f32
+
+pytestmark = pytest.mark.gpu
+OKW = dict(mode="tree", com_mode="true", drop_tail=False, max_depth=21)
+
+
+def crowd(n, half, seed, rmin=0.5, rmax=3.0):
+    rng = np.random.default_rng(seed)
+    pos = rng.uniform(-half, half, (n, 3))
+    vel = rng.normal(0, 1e-3, (n, 3))
+    mass = np.abs(rng.normal(1e3, 500, n)) + 1
+    rad = rng.uniform(rmin, rmax, n)
+    return pos, vel, mass, rad
+
+
+def run_engine(pos, vel, mass, rad, nsteps, precision="f64", **kw):
+    with Engine(mode="tree", precision=precision, collisions=True, **kw) as e:
+        e.upload(pos, vel, mass)
+        if rad is not None:
+            e.set_radius(rad)
+        per_step = []
+        for _ in range(nsteps):
+            e.step(1)
+            st = e.stats()
+            per_step.append((int(st.collision_pairs), int(st.merges), int(st.n_alive)))
+        p, v, m, ids = e.download()
+        r = e.get_radius()
+    return p, v, m, ids, r, per_step
+
+
+@pytest.mark.parametrize("seed,n,half", [(1, 2000, 60.0), (2, 5000, 100.0), (3, 300, 20.0)])
+def test_one_step_matches_the_oracle_exactly_in_structure(gpu, seed, n, half):
+    pos, vel, mass, rad = crowd(n, half, seed)
+    p, v, m, ids, r, per_step = run_engine(pos, vel, mass, rad, 1, theta=1.0, dt=100.0)
+    om, orad, op, ov, oalive, st = O.step_collide(mass, rad, pos, vel, nsteps=1, theta=1.0, dt=100.0, **OKW)
+    live = oalive == 1
+    assert st.merges > 10                                     # the scene does collide
+    assert per_step[0] == (st.queued, st.merges, int(live.sum()))
+    assert np.array_equal(ids, np.nonzero(live)[0].astype(np.uint64))
+    assert np.abs(m - om[live]).max() <= 1e-12 * om.max()
+    assert np.abs(r - orad[live]).max() <= 1e-14 * orad.max() + 1e-15
+    assert np.abs(v - ov[live]).max() <= 1e-11 * np.abs(ov[live]).max()
+    assert np.abs(p - op[live]).max() <= 1e-12 * np.abs(op[live]).max()
+
+
+def test_many_steps_follow_the_oracle(gpu):
+    """40 steps of a crowded scene: every step's queue length, the merges so far and the survivors agree."""
+    pos, vel, mass, rad = crowd(1500, 50.0, 11)
+    nsteps = 40
+    p, v, m, ids, r, per_step = run_engine(pos, vel, mass, rad, nsteps, theta=0.7, dt=50.0)
+    om, orad, op, ov, oalive = mass, rad, pos, vel, None
+    merges = 0
+    for s in range(nsteps):
+        om, orad, op, ov, oalive, st = O.step_collide(om, orad, op, ov, nsteps=1, alive=oalive, theta=0.7, dt=50.0, **OKW)
+        merges += st.merges
+        assert per_step[s] == (st.queued, merges, int(oalive.sum())), f"step {s}"
+    live = oalive == 1
+    assert merges > 50
+    assert np.array_equal(ids, np.nonzero(live)[0].astype(np.uint64))
+    assert np.abs(m - om[live]).max() <= 1e-12 * om.max()
+    assert np.abs(r - orad[live]).max() <= 1e-13 * orad.max()
+    assert np.abs(p - op[live]).max() <= 1e-9 * np.abs(op[live]).max()
+    assert np.abs(v - ov[live]).max() <= 1e-8 * np.abs(ov[live]).max()
+
+
+def test_combine_uses_the_summed_mass_as_the_reference_does(gpu):
+    """physics.go:154-158: a.Mass is overwritten before the velocities are mixed, so the merged velocity is
+    ((ma+mb)*va + mb*vb) / (ma + 2*mb), not the momentum-conserving one.  Two bodies 1 m apart in one small cell."""
+    pos = np.array([[100.25, 100.25, 100.25], [101.25, 100.25, 100.25], [-3000.0, 10.0, 10.0]])
+    vel = np.array([[1.0, 0.0, 0.0], [-2.0, 0.5, 0.0], [0.0, 0.0, 0.0]])
+    mass = np.array([3.0, 5.0, 1.0])
+    rad = np.array([1.0, 2.0, 1.0])
+    p, v, m, ids, r, per_step = run_engine(pos, vel, mass, rad, 1, dt=1e-3, G=0.0)
+    assert list(ids) == [0, 2] and per_step[0] == (2, 1, 2)          # queued from both sides, merged once
+    assert m[0] == 8.0 and abs(r[0] - (1.0 + 8.0) ** (1.0 / 3.0)) < 1e-15
+    want = (8.0 * vel[0] + 5.0 * vel[1]) / (8.0 + 5.0)
+    assert np.abs(v[0] - want).max() < 1e-15
+    assert np.abs(p[0] - (pos[0] + want * 1e-3)).max() < 1e-12
+
+
+def test_the_search_misses_neighbours_across_a_cell_boundary(gpu):
+    """tree.go:265-270: a body whose octant's doubled box holds its sphere searches only that octant.  Two bodies
+    0.5 m apart on either side of the root's x = 0 plane are never paired; the same pair shifted into one small
+    cell is."""
+    vel = np.zeros((3, 3)); mass = np.full(3, 10.0); rad = np.full(3, 1.0)
+    straddle = np.array([[-0.25, 500.3, 500.3], [0.25, 500.3, 500.3], [9000.0, 9000.0, 9000.0]])
+    p, v, m, ids, r, per_step = run_engine(straddle, vel, mass, rad, 1, dt=1e-3)
+    assert per_step[0] == (0, 0, 3)
+    q, _ = O.collision_queue(mass, rad, straddle, **{k: v for k, v in OKW.items() if k != "mode"})
+    assert len(q) == 0
+    inside = straddle + np.array([0.5, 0.0, 0.0])
+    p, v, m, ids, r, per_step = run_engine(inside, vel, mass, rad, 1, dt=1e-3)
+    assert per_step[0] == (2, 1, 2) and list(ids) == [0, 2]
+
+
+def test_merge_order_is_the_queue_order(gpu):
+    """Four bodies in one small cell that all touch: body 0 searches first and queues (0,1) (0,2) (0,3) in child
+    order; the merges happen in that order and the later pairs of absorbed bodies are dropped (main.go:161-163)."""
+    base = np.array([2000.0, 2000.0, 2000.0]) + 0.01
+    pos = base + np.array([[0.1, 0.1, 0.1], [0.6, 0.1, 0.1], [0.1, 0.6, 0.1], [0.6, 0.6, 0.6]])
+    vel = np.array([[1.0, 0, 0], [0, 1.0, 0], [0, 0, 1.0], [1.0, 1.0, 1.0]])
+    mass = np.array([1.0, 2.0, 3.0, 4.0]); rad = np.full(4, 0.5)
+    p, v, m, ids, r, per_step = run_engine(pos, vel, mass, rad, 1, dt=1e-3, G=0.0)
+    om, orad, op, ov, oalive, st = O.step_collide(mass, rad, pos, vel, nsteps=1, dt=1e-3, **OKW)
+    assert per_step[0] == (st.queued, st.merges, int(oalive.sum())) and st.merges == 3 and st.queued == 12
+    assert list(ids) == [0] and m[0] == 10.0
+    assert np.abs(v[0] - ov[0]).max() < 1e-15
+
+
+@pytest.mark.parametrize("precision", ["f32", "mixed"])
+def test_fp32_positions_take_the_same_decisions(gpu, precision):
+    """The collision test runs in fp64 on the positions the engine holds; with fp32-representable input the first
+    step queues and merges exactly what the oracle does."""
+    pos, vel, mass, rad = crowd(3000, 80.0, 5)
+    pos, vel, mass = f32(pos), f32(vel), f32(mass)
+    p, v, m, ids, r, per_step = run_engine(pos, vel, mass, rad, 1, precision=precision, theta=1.0, dt=100.0)
+    om, orad, op, ov, oalive, st = O.step_collide(mass, rad, pos, vel, nsteps=1, theta=1.0, dt=100.0, **OKW)
+    live = oalive == 1
+    assert per_step[0] == (st.queued, st.merges, int(live.sum()))
+    assert np.array_equal(ids, np.nonzero(live)[0].astype(np.uint64))
+    assert np.abs(m - om[live]).max() <= 2e-7 * om.max()
+    assert np.abs(r - orad[live]).max() <= 1e-13 * orad.max()
+    tol = 5e-6 if precision == "f32" else 1e-6
+    assert np.abs(v - ov[live]).max() <= tol * np.abs(ov[live]).max()
+    assert np.abs(p - op[live]).max() <= 1e-6 * np.abs(op[live]).max()
+
+
+def test_default_scene_with_the_reference_defaults(gpu):
+    """main.go:32-37 scene (1000 bodies + 2 cores, radius 2 and 1), tree, theta 1, collisions on: 60 steps."""
+    b = physics.makebodies(1000, seed=1)
+    nsteps = 60
+    p, v, m, ids, r, per_step = run_engine(b.pos, b.vel, b.mass, b.radius, nsteps)
+    om, orad, op, ov, oalive, st = O.step_collide(b.mass, b.radius, b.pos, b.vel, nsteps=nsteps, **OKW)
+    live = oalive == 1
+    assert per_step[-1][1] == st.merges and per_step[-1][2] == int(live.sum())
+    assert np.array_equal(ids, np.nonzero(live)[0].astype(np.uint64))
+    assert np.abs(m - om[live]).max() <= 1e-12 * om.max()
+    assert np.abs(p - op[live]).max() <= 1e-8 * np.abs(op[live]).max()
+
+
+def test_default_radius_is_two(gpu):
+    """nbe_upload gives every body physics.go:20's defaultRadius."""
+    pos, vel, mass, _ = crowd(500, 20.0, 8)
+    p, v, m, ids, r, per_step = run_engine(pos, vel, mass, None, 1, dt=10.0)
+    om, orad, op, ov, oalive, st = O.step_collide(mass, None, pos, vel, nsteps=1, dt=10.0, **OKW)
+    assert per_step[0] == (st.queued, st.merges, int(oalive.sum())) and st.merges > 0
+    assert np.abs(r - orad[oalive == 1]).max() < 1e-14
+
+
+def test_frames_leave_out_absorbed_bodies_and_carry_radii(gpu):
+    pos, vel, mass, rad = crowd(800, 30.0, 4)
+    got = []
+    with Engine(mode="tree", precision="f64", collisions=True, dt=20.0) as e:
+        e.upload(pos, vel, mass)
+        e.set_radius(rad)
+        e.frame_stream_begin(lambda f, xyzm, ids, radius: got.append((f, xyzm, ids, radius)), every=1, slots=4)
+        e.step(6)
+        e.frame_stream_end()
+        st = e.stats()
+    assert [g[0] for g in got] == list(range(6))
+    om, orad, op, ov, oalive = mass, rad, pos, vel, None
+    for s in range(6):
+        f, xyzm, ids, radius = got[s]
+        live = np.ones(len(mass), bool) if oalive is None else oalive == 1
+        order = np.argsort(ids)
+        assert np.array_equal(ids[order], np.nonzero(live)[0].astype(np.uint64)), f"frame {s}"
+        assert np.allclose(xyzm[order, 3], om[live], rtol=1e-6)
+        assert np.allclose(radius[order], orad[live], rtol=1e-6)
+        assert np.allclose(xyzm[order, :3], op[live], rtol=1e-5, atol=1e-4)
+        om, orad, op, ov, oalive, _ = O.step_collide(om, orad, op, ov, nsteps=1, alive=oalive, dt=20.0, **OKW)
+    assert int(st.n_alive) == int(oalive.sum())
+
+
+def test_accel_and_energy_after_merges(gpu):
+    """After a collision step the absorbed bodies are gone from forces, alive flags and the energy sums."""
+    pos, vel, mass, rad = crowd(600, 25.0, 6)
+    with Engine(mode="tree", precision="f64", collisions=True, dt=20.0, theta=0.0) as e:
+        e.upload(pos, vel, mass)
+        e.set_radius(rad)
+        e.step(1)
+        ke, pe, mom = e.energy()
+        p, v, m, ids = e.download()
+        acc, alive = e.accel()
+    om, orad, op, ov, oalive, st = O.step_collide(mass, rad, pos, vel, nsteps=1, dt=20.0, theta=0.0, **OKW)
+    assert np.array_equal(alive, oalive)
+    oke, ope, omom = O.energy(om, op, ov, alive=oalive)
+    assert abs(ke - oke) <= 1e-10 * abs(oke) and abs(pe - ope) <= 1e-10 * abs(ope)
+    f = O.direct_rows(om, op, alive=oalive)
+    live = oalive == 1
+    a_ref = f[live] / om[live][:, None]
+    err = np.linalg.norm(acc[live] - a_ref, axis=1) / np.linalg.norm(a_ref, axis=1)
+    assert err.max() <= 1e-9
+
+
+def test_unsupported_combinations_fail_loudly(gpu):
+    with pytest.raises(EngineError, match="tree mode"):
+        Engine(mode="direct", collisions=True)
+    pos, vel, mass, rad = crowd(100, 20.0, 1)
+    with Engine(mode="tree", collisions=True) as e:
+        e.upload(pos, vel, mass)
+        e.set_shard(0, 50)
+        with pytest.raises(EngineError, match="sharded"):
+            e.shard_prepare()
+        with pytest.raises(EngineError, match="negative"):
+            e.set_radius(-rad)
+    with Engine(mode="tree") as e:
+        e.upload(pos, vel, mass)
+        with pytest.raises(EngineError, match="collisions on"):
+            e.set_radius(rad)

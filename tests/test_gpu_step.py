@@ -121,7 +121,7 @@ def test_frame_stream_delivers_the_state_before_each_step(gpu, mode, precision):
     got = []
     with Engine(mode=mode, precision=precision, theta=0.7) as e:
         e.upload(b.pos, b.vel, b.mass, b.ids + 100)
-        e.frame_stream_begin(lambda f, xyzm, ids: got.append((f, xyzm, ids)), every=every, slots=2, first_frame=7)
+        e.frame_stream_begin(lambda f, xyzm, ids, radius: got.append((f, xyzm, ids)), every=every, slots=2, first_frame=7)
         e.step(nsteps)
         e.frame_stream_end()
         e.step(2)                      # streaming is off again

@@ -22,9 +22,9 @@ def read_frame(path):
     return rec
 
 
-def test_host_builds_and_insists_on_nocollision(tmp_path):
+def test_host_builds_and_the_direct_sum_insists_on_nocollision(tmp_path):
     assert os.path.exists(BIN), "build it with `make -C host` (or __graft_entry__.build())"
-    r = run(["-n", "10", "-y", "0.001"], tmp_path)
+    r = run(["-n", "10", "-y", "0.001"], tmp_path)          # collisions exist in tree mode only
     assert r.returncode == 2 and b"-nocollision" in r.stdout
     r = run(["-bogus"], tmp_path)
     assert r.returncode == 2 and b"flag provided but not defined" in r.stdout
@@ -67,3 +67,19 @@ def test_host_frame_loop_save_and_resume(gpu, tmp_path, tree):
     # -norender runs the same loop without frames
     r = run(["-n", "500", "-y", "0.002", "-nocollision", "-norender"] + mode, tmp_path)
     assert r.returncode == 0 and b"Done. Took" in r.stdout
+
+
+@pytest.mark.gpu
+def test_host_tree_run_with_collisions(gpu, tmp_path):
+    """The reference's default is collisions on (main.go:24); in tree mode the host runs them on the GPU.  A dense
+    seed scene loses bodies, the frames shrink with it and carry the merged radii."""
+    r = run(["-n", "3000", "-y", "0.003", "-tree", "-seed", "3", "-save"], tmp_path)        # frames = 26
+    assert r.returncode == 0, r.stdout.decode()
+    assert "collisions: true" in r.stdout.decode()
+    files = sorted(os.listdir(tmp_path / "frames"))
+    assert files == [f"{k:010d}.frame" for k in range(27)]
+    first, last = read_frame(tmp_path / "frames" / files[0]), read_frame(tmp_path / "frames" / files[-1])
+    assert len(first) == 3002 and len(last) <= len(first)
+    assert abs(float(first["xyzmr"][:, 3].sum()) - float(last["xyzmr"][:, 3].sum())) <= 1e-3 * float(first["xyzmr"][:, 3].sum())
+    if len(last) < len(first):
+        assert last["xyzmr"][:, 4].max() > 2.0            # cbrt(2^3 + 2^3) > 2
