@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void emit_cnodes_kernel(int n, const int* __re
     const int na = counters[0];
     const int t = blockIdx.x * 256 + threadIdx.x;
     CNode c;
-    c.pmask = 0; c.pad0 = 0; c.pad1 = 0;
+    c.pmask = 0; c.pad0 = 0; c.parent = -1;
     if (t < n) {
         if (t >= na) return;
         const int pos = t + (int)cellcnt[t + 1];
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void emit_cnodes_kernel(int n, const int* __re
     cn[pos] = c;
 }
 
-// Every branching cell tells its children which of its octants are occupied.
+// Every branching cell tells its children where it is and which of its octants are occupied.
 __global__ __launch_bounds__(256) void cnode_parents_kernel(const int* __restrict__ counters, CNode* __restrict__ cn)
 {
     const int total = counters[1];
@@ -88,53 +88,80 @@ __global__ __launch_bounds__(256) void cnode_parents_kernel(const int* __restric
     if (level >= 21) mask = 0xff;                             // bucket of equal keys: no octants below
     else
         for (int c = p + 1; c < end; c = cn[c].skip) mask |= 1u << ((unsigned)(cn[c].key >> (3 * (20 - level))) & 7u);
-    for (int c = p + 1; c < end; c = cn[c].skip) cn[c].pmask = (uint8_t)mask;
+    for (int c = p + 1; c < end; c = cn[c].skip) { cn[c].pmask = (uint8_t)mask; cn[c].parent = p; }
+}
+
+// Is the search of a body at (px,py,pz) with radius R confined to one child of the cell `pc`?  tree.go:265-270:
+// the octant the body falls into must exist (`mask`) and its doubled box must hold the sphere.  *oct_out is that octant.
+__device__ __forceinline__ bool confined(const Cell& pc, unsigned mask, double px, double py, double pz, double R, int* oct_out)
+{
+    const int oct = (px - pc.cx >= 0.0 ? 1 : 0) | (py - pc.cy >= 0.0 ? 2 : 0) | (pz - pc.cz >= 0.0 ? 4 : 0);
+    *oct_out = oct;
+    if (!((mask >> oct) & 1u)) return false;
+    const double q = 0.25 * pc.w, cw = 0.5 * pc.w - R;          // the child's bound: half the edge
+    const double ccx = pc.cx + ((oct & 1) ? q : -q), ccy = pc.cy + ((oct & 2) ? q : -q), ccz = pc.cz + ((oct & 4) ? q : -q);
+    return fabs(px - ccx) <= cw && fabs(py - ccy) <= cw && fabs(pz - ccz) <= cw;
 }
 
 // tree.go:245-281 for sorted body t.  FILL = false counts the pairs the body queues (into count[upload index]);
 // FILL = true writes them at offset[upload index] in the order the recursion meets them (children 0..7).
 //
-// A body can only find anything where its descent stops being confined to its own octant: at a cell above it whose
-// child is too small for containsSphere (child edge - r < offset), i.e. cell edge < 4r.  Bodies whose deepest
-// enclosing branching cell is wider than that walk straight down to their own leaf and return (tree.go:246-248);
-// they are answered from the keys of their two neighbours without touching the tree.
+// From the root down, the recursion stays confined to the body's own octant for as long as containsSphere holds
+// for the child it is in, which it does at every cell with edge >= 4r (the body is inside the child, at most half
+// a child edge from its centre, and the test allows a full child edge minus r).  Cells on the way down always
+// pass intersectSphere, because the body is inside them.  So the search proper starts at the SHALLOWEST cell above
+// the body where the confinement fails: found by climbing from the body's leaf through the cells with edge < 4r.
+// If there is none, the recursion ends at the body's own leaf (tree.go:246-248) with nothing queued.  Below that
+// cell every node is judged as the recursion would judge it, by the decision its parent takes for it.
 template <typename R4, bool FILL>
 __global__ __launch_bounds__(256) void collide_search_kernel(const CNode* __restrict__ cn, const int* __restrict__ counters,
                                                              const uint64_t* __restrict__ keys, const R4* __restrict__ posm,
                                                              const double* __restrict__ radius, const uint32_t* __restrict__ orig,
+                                                             const uint32_t* __restrict__ cellcnt,
                                                              double lox, double loy, double loz, double W,
                                                              uint32_t* __restrict__ count, const uint32_t* __restrict__ offset,
                                                              int2* __restrict__ pairs)
 {
-    const int na = counters[0], total = counters[1];
+    const int na = counters[0];
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t >= na || na < 2) return;
     const double R = radius[t];
+    const double reach = 4.000001 * R;                 // cells at least this wide confine the search for certain
     {
+        // the deepest cell above the body is the one it shares with its nearer neighbour in key order
         const uint64_t ki = keys[t];
         const int dl = key_delta(keys, na, t, ki, t - 1), dr = key_delta(keys, na, t, ki, t + 1);
         const int lp = delta_level(dl > dr ? dl : dr);
-        if (lp < 21 && ldexp(W, -lp) > 4.000001 * R) return;
+        if (lp < 21 && ldexp(W, -lp) > reach) return;
     }
     const R4 p4 = posm[t];
     const double px = (double)p4.x, py = (double)p4.y, pz = (double)p4.z;
+    int top = -1;                                      // shallowest cell above the body that does not confine it
+    for (int c = cn[t + (int)cellcnt[t + 1]].parent; c >= 0;) {
+        const CNode nd = cn[c];
+        if (nd.level >= 21) top = c;                   // bucket of equal keys: all of its leaves are searched
+        else {
+            const Cell pc = cell_of(nd.key, nd.level, lox, loy, loz, W);
+            if (pc.w > reach) break;
+            // octants present under this cell: the mask its children carry
+            int oct;
+            if (!confined(pc, cn[c + 1].pmask, px, py, pz, R, &oct)) top = c;
+        }
+        c = nd.parent;
+    }
+    if (top < 0) return;
     const uint32_t base = FILL ? offset[orig[t]] : 0u;
     uint32_t found = 0;
-    int cur = 0;
-    while (cur < total) {
+    const int end = cn[top].skip;
+    int cur = top + 1;
+    while (cur < end) {
         const CNode nd = cn[cur];
         bool visit = true;
         if (nd.plevel < 21) {
             // the decision the cell above took for this child (tree.go:265-279)
-            const Cell pc = cell_of(nd.key, nd.plevel, lox, loy, loz, W);
-            const int oct = (px - pc.cx >= 0.0 ? 1 : 0) | (py - pc.cy >= 0.0 ? 2 : 0) | (pz - pc.cz >= 0.0 ? 4 : 0);
-            if ((nd.pmask >> oct) & 1) {
-                const double q = 0.25 * pc.w, cw = 0.5 * pc.w - R;          // the child's bound: half the edge
-                const double ccx = pc.cx + ((oct & 1) ? q : -q), ccy = pc.cy + ((oct & 2) ? q : -q),
-                             ccz = pc.cz + ((oct & 4) ? q : -q);
-                if (fabs(px - ccx) <= cw && fabs(py - ccy) <= cw && fabs(pz - ccz) <= cw)
-                    visit = (int)((unsigned)(nd.key >> (3 * (20 - nd.plevel))) & 7u) == oct;
-            }
+            int oct;
+            if (confined(cell_of(nd.key, nd.plevel, lox, loy, loz, W), nd.pmask, px, py, pz, R, &oct))
+                visit = (int)((unsigned)(nd.key >> (3 * (20 - nd.plevel))) & 7u) == oct;
         }
         if (!visit || nd.body == t) { cur = nd.skip; continue; }              // tree.go:246-248
         const Cell c = cell_of(nd.key, nd.level < 21 ? nd.level : 21, lox, loy, loz, W);
@@ -157,40 +184,71 @@ __global__ __launch_bounds__(256) void collide_search_kernel(const CNode* __rest
     if (!FILL) count[orig[t]] = found;
 }
 
-// main.go:160-166 with combine (physics.go:153-162), one pair after the other: the outcome depends on the order.
+// combine (physics.go:153-162) for one queued pair, unless an earlier merge removed one of the two (main.go:161-163).
 // Accelerations stand in for the reference's force accumulators: f = a*m before the merge, a = (fa + fb) / M
 // after it.  a.Mass is the sum already when the velocities are mixed, as the reference writes it.
 template <typename A4>
-__global__ void collide_merge_kernel(const int2* __restrict__ pairs, const uint32_t* __restrict__ total_ptr, A4* __restrict__ posm,
-                                     A4* __restrict__ vel, A4* __restrict__ acc, double* __restrict__ radius,
-                                     uint8_t* __restrict__ dead, float4* __restrict__ mirror, int* __restrict__ counters)
+__device__ __forceinline__ int merge_pair(int a, int b, A4* __restrict__ posm, A4* __restrict__ vel, A4* __restrict__ acc,
+                                          double* __restrict__ radius, uint8_t* __restrict__ dead, float4* __restrict__ mirror)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (dead[a] || dead[b]) return 0;
+    A4 pa = posm[a], va = vel[a], fa = acc[a];
+    const A4 pb = posm[b], vb = vel[b], fb = acc[b];
+    const auto ma = pa.w, mb = pb.w;
+    const auto M = ma + mb;
+    const double ra = radius[a], rb = radius[b];
+    radius[a] = cbrt(ra * ra * ra + rb * rb * rb);
+    va.x = (M * va.x + mb * vb.x) / (M + mb);
+    va.y = (M * va.y + mb * vb.y) / (M + mb);
+    va.z = (M * va.z + mb * vb.z) / (M + mb);
+    fa.x = (fa.x * ma + fb.x * mb) / M;
+    fa.y = (fa.y * ma + fb.y * mb) / M;
+    fa.z = (fa.z * ma + fb.z * mb) / M;
+    pa.w = M;
+    posm[a] = pa; vel[a] = va; acc[a] = fa;
+    if (mirror) mirror[a].w = (float)M;
+    dead[b] = 1;
+    return 1;
+}
+
+// main.go:160-166: the queue is worked off in order, and the outcome depends on that order wherever pairs share
+// a body.  One wave takes 64 queue entries at a time: entries that share no body with an earlier entry of the
+// same 64 cannot be affected by them and are merged side by side; the others follow one at a time in queue order.
+// Entries of earlier 64s are finished (and their stores fenced) before the next 64 are read.
+template <typename A4>
+__global__ __launch_bounds__(64) void collide_merge_kernel(const int2* __restrict__ pairs, const uint32_t* __restrict__ total_ptr,
+                                                           A4* __restrict__ posm, A4* __restrict__ vel, A4* __restrict__ acc,
+                                                           double* __restrict__ radius, uint8_t* __restrict__ dead,
+                                                           float4* __restrict__ mirror, int* __restrict__ counters)
+{
+    if (blockIdx.x != 0) return;
+    const int lane = threadIdx.x;
     const uint32_t total = *total_ptr;
     int merged = 0;
-    for (uint32_t q = 0; q < total; q++) {
-        const int a = pairs[q].x, b = pairs[q].y;
-        if (dead[a] || dead[b]) continue;
-        A4 pa = posm[a], va = vel[a], fa = acc[a];
-        const A4 pb = posm[b], vb = vel[b], fb = acc[b];
-        const auto ma = pa.w, mb = pb.w;
-        const auto M = ma + mb;
-        const double ra = radius[a], rb = radius[b];
-        radius[a] = cbrt(ra * ra * ra + rb * rb * rb);
-        va.x = (M * va.x + mb * vb.x) / (M + mb);
-        va.y = (M * va.y + mb * vb.y) / (M + mb);
-        va.z = (M * va.z + mb * vb.z) / (M + mb);
-        fa.x = (fa.x * ma + fb.x * mb) / M;
-        fa.y = (fa.y * ma + fb.y * mb) / M;
-        fa.z = (fa.z * ma + fb.z * mb) / M;
-        pa.w = M;
-        posm[a] = pa; vel[a] = va; acc[a] = fa;
-        if (mirror) mirror[a].w = (float)M;
-        dead[b] = 1;
-        merged++;
+    for (uint32_t q0 = 0; q0 < total; q0 += 64) {
+        const bool have = q0 + lane < total;
+        int a = -1 - lane, b = -65 - lane;            // lanes without an entry match nobody
+        if (have) { const int2 pr = pairs[q0 + lane]; a = pr.x; b = pr.y; }
+        bool shares = false;
+        for (int j = 0; j < 63; j++) {
+            const int aj = __shfl(a, j, 64), bj = __shfl(b, j, 64);
+            if (j < lane && (aj == a || aj == b || bj == a || bj == b)) shares = true;
+        }
+        if (have && !shares) merged += merge_pair(a, b, posm, vel, acc, radius, dead, mirror);
+        __threadfence_block();
+        unsigned long long rest = __ballot(have && shares);
+        while (rest) {
+            const int k = __ffsll((long long)rest) - 1;
+            if (lane == k) merged += merge_pair(a, b, posm, vel, acc, radius, dead, mirror);
+            __threadfence_block();
+            rest &= rest - 1;
+        }
     }
-    counters[3] += merged;      // absorbed since the last sort
-    counters[6] += merged;      // absorbed since upload
+    for (int d = 32; d >= 1; d >>= 1) merged += __shfl_down(merged, d, 64);
+    if (lane == 0) {
+        counters[3] += merged;      // absorbed since the last sort
+        counters[6] += merged;      // absorbed since upload
+    }
 }
 
 // physics.go:101-115 for the survivors, from the acceleration buffer.  An absorbed body is parked outside the
@@ -299,7 +357,8 @@ static int collide_and_update_t(nbe_engine* e, const void* force_pos)
 
     NBE_HIP(hipMemsetAsync(w.count, 0, ((size_t)n + 1) * 4, e->stream));
     hipLaunchKernelGGL((collide_search_kernel<R4, false>), grid, block, 0, e->stream, w.cnodes, t.counters, t.keys[0],
-                       (const R4*)force_pos, e->radius[cur], e->orig[e->orig_cur], lox, loy, loz, W, w.count, w.offset, w.pairs);
+                       (const R4*)force_pos, e->radius[cur], e->orig[e->orig_cur], t.cellcnt, lox, loy, loz, W, w.count, w.offset,
+                       w.pairs);
     NBE_HIP(hipGetLastError());
     NBE_TRY(device_scan_u32(e, w.count, w.offset, (size_t)n + 1));
     uint32_t total = 0;
@@ -313,8 +372,8 @@ static int collide_and_update_t(nbe_engine* e, const void* force_pos)
             NBE_HIP(hipMalloc((void**)&w.pairs, w.pairs_cap * sizeof(int2)));
         }
         hipLaunchKernelGGL((collide_search_kernel<R4, true>), grid, block, 0, e->stream, w.cnodes, t.counters, t.keys[0],
-                           (const R4*)force_pos, e->radius[cur], e->orig[e->orig_cur], lox, loy, loz, W, w.count, w.offset,
-                           w.pairs);
+                           (const R4*)force_pos, e->radius[cur], e->orig[e->orig_cur], t.cellcnt, lox, loy, loz, W, w.count,
+                           w.offset, w.pairs);
         hipLaunchKernelGGL((collide_merge_kernel<A4>), dim3(1), dim3(64), 0, e->stream, w.pairs, w.offset + n, (A4*)e->posm[cur],
                            (A4*)e->vel[cur], (A4*)e->acc, e->radius[cur], w.dead, mixed ? e->mirror[cur] : (float4*)nullptr,
                            t.counters);

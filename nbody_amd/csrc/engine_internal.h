@@ -88,7 +88,7 @@ struct CNode {
     uint8_t plevel;     // depth of the branching cell above, 255 for the root
     uint8_t pmask;      // which octants of that cell hold bodies (bit o = child o exists, tree.go:266)
     uint8_t pad0;
-    uint32_t pad1;
+    int parent;         // pre-order index of that cell, -1 for the root
 };
 static_assert(sizeof(CNode) == 24, "CNode must be 24 bytes");
 
