@@ -181,11 +181,14 @@ class Simulation:
     main.go:104-178 (collisions off); `frame()` is the copy of live bodies taken at main.go:90-101."""
 
     def __init__(self, bodies, tree=False, theta=THETA, dt=DT, eps=0.0, precision="f32", device=0,
-                 bound_width=BOUND_WIDTH):
+                 bound_width=BOUND_WIDTH, nocollision=True):
         self.bodies = bodies
+        self.collisions = not nocollision                     # main.go:24; tree mode only
         self.engine = Engine(mode="tree" if tree else "direct", precision=precision, theta=theta, dt=dt, eps=eps,
-                             bound_width=bound_width, device=device)
+                             bound_width=bound_width, device=device, collisions=self.collisions)
         self.engine.upload(bodies.pos, bodies.vel, bodies.mass, bodies.ids)
+        if self.collisions:
+            self.engine.set_radius(bodies.radius)
         self.frame_index = 0
 
     def step(self, nsteps=1):
@@ -194,7 +197,28 @@ class Simulation:
 
     def frame(self):
         pos, vel, mass, ids = self.engine.download()
-        return Bodies(pos, vel, mass, ids)
+        if self.collisions:
+            return Bodies(pos, vel, mass, ids, self.engine.get_radius())
+        radius_of = dict(zip(self.bodies.ids.tolist(), self.bodies.radius.tolist()))
+        return Bodies(pos, vel, mass, ids, [radius_of[int(i)] for i in ids])
+
+    def run(self, frames, sink, iter_per_frame=1, start_frame=0, slots=32):
+        """The frame loop of main.go:80-190 with a sink behind the frame channel: frames+1 iterations, each
+        sending the state BEFORE its step (main.go:90-101) to `sink.write(frame, ids, xyzm, radius)` from the
+        engine's delivery thread, then stepping iter_per_frame times (main.go:104)."""
+        radius_of = dict(zip(self.bodies.ids.tolist(), self.bodies.radius.tolist()))
+
+        def on_frame(frame, xyzm, ids, radius):
+            if radius is None:
+                radius = np.array([radius_of[int(i)] for i in ids])
+            sink.write(frame, ids, xyzm, radius)
+
+        self.engine.frame_stream_begin(on_frame, every=iter_per_frame, slots=slots, first_frame=start_frame)
+        try:
+            for _ in range(start_frame, frames + 1):
+                self.step(iter_per_frame)
+        finally:
+            self.engine.frame_stream_end()
 
     def close(self):
         self.engine.close()
