@@ -465,6 +465,10 @@ static int fetch_interactions(nbe_engine* e)
         NBE_HIP(hipMemcpyAsync(v, e->tw.d_interactions, sizeof(v), hipMemcpyDeviceToHost, e->stream));
         NBE_HIP(hipStreamSynchronize(e->stream));
         e->stats.interactions = v[0];
+#ifdef WALK_VISIT_STATS
+        fprintf(stderr, "walk visits: sum %llu max %llu sumsq %llu hist(<3000,<4000,<6000,>=6000) %llu %llu %llu %llu\n", v[1], v[2],
+                v[3], v[4], v[5], v[6], v[7]);
+#endif
     }
     return NBE_OK;
 }

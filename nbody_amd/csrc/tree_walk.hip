@@ -57,6 +57,10 @@ __device__ __forceinline__ double as_real(unsigned long long v) { return __longl
 __device__ __forceinline__ bool node_opens(const RawF& nd, float r2, float) { return r2 < as_real(nd.w2); }
 __device__ __forceinline__ bool node_opens(const RawD& nd, double r2, double theta) { return as_real(nd.w) / sqrt(r2) > theta; }
 
+#ifndef WALK_BLOCK
+#define WALK_BLOCK 256
+#endif
+
 // COUNT: instrumented pass: also counts the force evaluations (tree.go:232-238 executions) of the wave and sums
 // each body's potential (sum of mass / softened distance over the same accepted nodes, returned in the w
 // component of the acceleration record, without the factor -G); the production step runs without it.
@@ -71,7 +75,7 @@ __device__ __forceinline__ bool node_opens(const RawD& nd, double r2, double the
 // in s_waitcnt for 47 % of their cycles even at 8 waves per SIMD: the limit is the scalar cache's miss
 // throughput, not arithmetic (16 VALU + 8 SALU instructions per visit) and not HBM.
 template <typename R, typename A, typename NodeT, int OUT, bool COUNT, bool SOFT, int NS>
-__global__ __launch_bounds__(256) void walk_kernel(
+__global__ __launch_bounds__(WALK_BLOCK) void walk_kernel(
     const NodeT* __restrict__ nodes, const int* __restrict__ counters, const typename V4<R>::type* __restrict__ posm,
     int t0, int t1, R theta, R floor2, A G, A dt, typename V4<A>::type* __restrict__ acc_out,
     const typename V4<A>::type* __restrict__ pos_in, const typename V4<A>::type* __restrict__ vel_in,
@@ -90,7 +94,7 @@ __global__ __launch_bounds__(256) void walk_kernel(
     // grid size; a placement assumption that only affects speed).
     const unsigned nwg = gridDim.x, q8 = nwg / 8, r8 = nwg % 8, xcd = blockIdx.x % 8;
     const unsigned wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + blockIdx.x / 8;
-    const int ibase = t0 + (int)wg * (256 * NS) + threadIdx.x;
+    const int ibase = t0 + (int)wg * (WALK_BLOCK * NS) + threadIdx.x;
     if (__ballot(ibase < tend) == 0) return;     // whole wave past the end (group 0 holds its lowest bodies)
 
     bool valid[NS];
@@ -101,7 +105,7 @@ __global__ __launch_bounds__(256) void walk_kernel(
     unsigned count = 0;
 #pragma unroll
     for (int s = 0; s < NS; s++) {
-        const int i = ibase + s * 256;
+        const int i = ibase + s * WALK_BLOCK;
         valid[s] = i < tend;
         px[s] = 0; py[s] = 0; pz[s] = 0;
         if (valid[s]) { R4 p = posm[i]; px[s] = p.x; py[s] = p.y; pz[s] = p.z; }
@@ -114,10 +118,14 @@ __global__ __launch_bounds__(256) void walk_kernel(
     // (Fetching both possible successors ahead of the vote was slower: the scalar unit is shared by the CU's
     // four SIMDs, and the extra loads and selects cost more than the latency they hid.)
     for (;;) {
-        bool more = false;
+        if (NS == 1) {
+            if (cur[0] >= total) break;
+        } else {
+            bool more = false;
 #pragma unroll
-        for (int s = 0; s < NS; s++) more = more || cur[s] < total;
-        if (!more) break;
+            for (int s = 0; s < NS; s++) more = more || cur[s] < total;
+            if (!more) break;
+        }
 #pragma unroll
         for (int s = 0; s < NS; s++) {
             const auto nd = load_raw(nodes, cur[s]);
@@ -144,7 +152,8 @@ __global__ __launch_bounds__(256) void walk_kernel(
             }
             cur[s] = __builtin_amdgcn_ballot_w64(open) != 0 ? cur[s] + 1 : skip;
         }
-        if (BLOCKED && ((++it) & 63) == 0) {
+        ++it;
+        if (BLOCKED && (it & 63) == 0) {
 #pragma unroll
             for (int s = 0; s < NS; s++) {
                 ax[s] += (A)fx[s]; ay[s] += (A)fy[s]; az[s] += (A)fz[s];
@@ -153,11 +162,19 @@ __global__ __launch_bounds__(256) void walk_kernel(
         }
     }
 
-    if (COUNT && (threadIdx.x & 63) == 0 && interactions) atomicAdd(interactions, (unsigned long long)count);
+    if (COUNT && (threadIdx.x & 63) == 0 && interactions) {
+        atomicAdd(interactions, (unsigned long long)count);
+#ifdef WALK_VISIT_STATS
+        atomicAdd(interactions + 1, (unsigned long long)it);
+        atomicMax(interactions + 2, (unsigned long long)it);
+        atomicAdd(interactions + 3, (unsigned long long)it * (unsigned long long)it);
+        atomicAdd(interactions + 4 + (it >= 3000) + (it >= 4000) + (it >= 6000), 1ull);
+#endif
+    }
 #pragma unroll
     for (int s = 0; s < NS; s++) {
         if (!valid[s]) continue;
-        const int i = ibase + s * 256;
+        const int i = ibase + s * WALK_BLOCK;
         const A sx = ax[s] + (A)fx[s], sy = ay[s] + (A)fy[s], sz = az[s] + (A)fz[s];
         if (OUT == OUT_ACC) {
             A4 o; o.x = G * sx; o.y = G * sy; o.z = G * sz; o.w = phi[s];
@@ -208,21 +225,21 @@ static int launch_walk(nbe_engine* e, const void* src, uint64_t t0, uint64_t t1,
     A4* pos_out = (A4*)e->posm[dst_buf];
     A4* vel_out = (A4*)e->vel[dst_buf];
     float4* mirror_out = mixed ? e->mirror[dst_buf] : nullptr;
-    dim3 grid(cdiv(nt, 256 * WALK_NS));
+    dim3 grid(cdiv(nt, WALK_BLOCK * WALK_NS));
     dim3 cgrid(cdiv(nt, 256));
     if (fused) {
-        WALK_LAUNCH(OUT_FUSED, false) grid, dim3(256), 0, e->stream, (const NodeT*)e->tw.nodes,
+        WALK_LAUNCH(OUT_FUSED, false) grid, dim3(WALK_BLOCK), 0, e->stream, (const NodeT*)e->tw.nodes,
                            e->tw.counters, (const R4*)src, (int)t0, (int)t1, (R)e->cfg.theta, floor2, G, dt, (A4*)e->acc,
                            pos_in, vel_in, pos_out, vel_out, mirror_out, e->tw.d_interactions);
         hipLaunchKernelGGL((carry_dead_kernel<A4>), cgrid, dim3(256), 0, e->stream, e->tw.counters, (int)t0, (int)t1, pos_in,
                            vel_in, mixed ? e->mirror[src_buf] : (const float4*)nullptr, pos_out, vel_out, mirror_out);
     } else if (count) {
         NBE_HIP(hipMemsetAsync(e->tw.d_interactions, 0, 8 * sizeof(unsigned long long), e->stream));
-        WALK_LAUNCH(OUT_ACC, true) grid, dim3(256), 0, e->stream, (const NodeT*)e->tw.nodes,
+        WALK_LAUNCH(OUT_ACC, true) grid, dim3(WALK_BLOCK), 0, e->stream, (const NodeT*)e->tw.nodes,
                            e->tw.counters, (const R4*)src, (int)t0, (int)t1, (R)e->cfg.theta, floor2, G, dt, (A4*)e->acc,
                            pos_in, vel_in, pos_out, vel_out, mirror_out, e->tw.d_interactions);
     } else {
-        WALK_LAUNCH(OUT_ACC, false) grid, dim3(256), 0, e->stream, (const NodeT*)e->tw.nodes,
+        WALK_LAUNCH(OUT_ACC, false) grid, dim3(WALK_BLOCK), 0, e->stream, (const NodeT*)e->tw.nodes,
                            e->tw.counters, (const R4*)src, (int)t0, (int)t1, (R)e->cfg.theta, floor2, G, dt, (A4*)e->acc,
                            pos_in, vel_in, pos_out, vel_out, mirror_out, e->tw.d_interactions);
     }
