@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -80,6 +81,11 @@ extern "C" int nbe_create(const nbe_config* cfg, nbe_engine** out)
     e->state64 = cfg->precision != NBE_PREC_F32;
     e->force64 = cfg->precision == NBE_PREC_F64;
     e->elem = e->state64 ? 32 : 16;
+    e->small_max = tree_small_limit();
+    if (const char* env = getenv("NBODY_SMALL_TREE_MAX")) {     // test knob: 0 sends every size down the tiled path
+        const long v = strtol(env, nullptr, 10);
+        if (v >= 0 && v < e->small_max) e->small_max = (int)v;
+    }
     int rc = use_device(e);
     if (rc == NBE_OK && hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking) != hipSuccess) {
         nbe_set_error("hipStreamCreate failed");

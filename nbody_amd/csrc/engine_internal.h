@@ -149,6 +149,7 @@ struct nbe_engine {
     CollWork cw;
     int orig_cur = 0;
     int cur = 0;
+    int small_max = 0;              // tree mode: up to this many bodies take the single-workgroup sort and scans
     bool timing = false;            // record phase events during the next step
     bool have_counts = false;       // tw.counters hold the result of a build of this upload
     uint64_t* ids = nullptr;        // host copy of body IDs in upload order
@@ -174,6 +175,7 @@ struct nbe_engine {
 int direct_forces(nbe_engine* e, int src_buf, uint64_t t0, uint64_t t1, bool fused, int dst_buf);
 // tree_build.hip
 int tree_workspace_reserve(nbe_engine* e);
+int tree_small_limit(void);
 int tree_sort_and_build(nbe_engine* e);         // sorts cur -> cur^1, flips e->cur, builds the tree
 // tree_walk.hip
 int tree_forces(nbe_engine* e, int src_buf, uint64_t t0, uint64_t t1, bool fused, bool count, int dst_buf);

@@ -116,10 +116,38 @@ __global__ __launch_bounds__(256) void scan_apply_kernel(const uint32_t* __restr
     }
 }
 
+// Short inputs: one workgroup walks the tiles with a running carry (one launch instead of three).
+template <bool POPC>
+__global__ __launch_bounds__(256) void scan_single_kernel(const uint32_t* __restrict__ in, size_t len, uint32_t* __restrict__ out)
+{
+    uint32_t carry = 0;
+    for (size_t base = 0; base < len; base += SCAN_TILE) {
+        const size_t b = base + (size_t)threadIdx.x * 8;
+        uint32_t v[8], s = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) { v[k] = scan_load<POPC>(in, b + k, len); s += v[k]; }
+        uint32_t tot;
+        uint32_t off = carry + block_excl_scan(s, &tot);
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            if (b + k < len) out[b + k] = off;
+            off += v[k];
+        }
+        carry += tot;
+    }
+}
+
+#define SCAN_SINGLE_MAX (8 * SCAN_TILE)
+
 template <bool POPC>
 static int device_exclusive_scan(nbe_engine* e, const uint32_t* in, uint32_t* out, size_t len)
 {
     if (len == 0) return NBE_OK;
+    if (len <= SCAN_SINGLE_MAX && e->small_max > 0) {
+        hipLaunchKernelGGL((scan_single_kernel<POPC>), dim3(1), dim3(256), 0, e->stream, in, len, out);
+        NBE_HIP(hipGetLastError());
+        return NBE_OK;
+    }
     const unsigned nblk = cdiv(len, SCAN_TILE);
     if (nblk > e->tw.scan_tmp_len) { nbe_set_error("scan workspace too small"); return NBE_E_INVALID; }
     hipLaunchKernelGGL((scan_reduce_kernel<POPC>), dim3(nblk), dim3(256), 0, e->stream, in, len, e->tw.scan_tmp);
@@ -142,6 +170,15 @@ __device__ __forceinline__ uint32_t cell_index(double x, double lo, double cell)
     return (uint32_t)q;
 }
 
+// Key of one body: KEY_DEAD unless lo <= p < hi on every axis.
+__device__ __forceinline__ uint64_t body_key(double x, double y, double z, double lox, double loy, double loz, double width)
+{
+    const bool in = (lox <= x && x < lox + width) && (loy <= y && y < loy + width) && (loz <= z && z < loz + width);
+    if (!in) return KEY_DEAD;
+    const double cell = width * (1.0 / 2097152.0);    // 2^21 cells per axis at depth 21
+    return spread3(cell_index(x, lox, cell)) | (spread3(cell_index(y, loy, cell)) << 1) | (spread3(cell_index(z, loz, cell)) << 2);
+}
+
 // One key per body.  A body is kept iff lo <= p < hi on every axis (contains, tree.go:65-72; NaN fails);
 // others get the all-ones key, sort to the end and stay out of the tree for good (tree.go:290-292).
 // (Counting the live bodies here with one atomic per wave cost 180 us at 1M bodies: 16k atomics on one word.)
@@ -151,22 +188,11 @@ __global__ __launch_bounds__(256) void keys_kernel(const R4* __restrict__ posm, 
                                                    int* __restrict__ counters)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    int alive = 0;
     if (i < n) {
         R4 p = posm[i];
-        const double x = (double)p.x, y = (double)p.y, z = (double)p.z;
-        const bool in = (lox <= x && x < lox + width) && (loy <= y && y < loy + width) && (loz <= z && z < loz + width);
-        uint64_t key = KEY_DEAD;
-        if (in) {
-            const double cell = width * (1.0 / 2097152.0);    // 2^21 cells per axis at depth 21
-            key = spread3(cell_index(x, lox, cell)) | (spread3(cell_index(y, loy, cell)) << 1) |
-                  (spread3(cell_index(z, loz, cell)) << 2);
-            alive = 1;
-        }
-        keys[i] = key;
+        keys[i] = body_key((double)p.x, (double)p.y, (double)p.z, lox, loy, loz, width);
         idx[i] = (uint32_t)i;
     }
-    (void)alive;
     (void)counters;   // the number of live bodies falls out of the sort: see set_alive_count_kernel
 }
 
@@ -277,6 +303,116 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const uint64_t* __re
             kout[pos] = key;
             vout[pos] = sval[slot];
         }
+    }
+}
+
+// ---- few bodies: keys and the whole sort in one workgroup ------------------------------------------------------------
+// Up to SMALL_SORT_MAX bodies: 16 waves hold 8 keys per lane in registers and run the eight 8-bit passes through
+// LDS with the same stable ballot ranking as above; one launch replaces the 41 of the tiled sort, which at this
+// size are nothing but launch latency.  Also counts the live bodies.
+#define SMALL_SORT_MAX 8192
+#define SMALL_WAVES 16
+#define SMALL_KPT 8      // SMALL_WAVES * 64 * SMALL_KPT == SMALL_SORT_MAX
+
+template <typename R4>
+__global__ __launch_bounds__(1024) void small_sort_kernel(const R4* __restrict__ posm, int n, double lox, double loy, double loz,
+                                                          double width, uint64_t* __restrict__ keys_out,
+                                                          uint32_t* __restrict__ idx_out, int* __restrict__ counters)
+{
+    __shared__ uint64_t skey[SMALL_SORT_MAX];
+    __shared__ uint32_t sval[SMALL_SORT_MAX];
+    __shared__ uint32_t wcount[SMALL_WAVES][256];   // per wave and digit: count, then offset within the digit
+    __shared__ uint32_t dbase[256];
+    __shared__ uint32_t wsum[SMALL_WAVES];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // each wave owns a contiguous run of 64 * rounds slots, rounds = keys per lane actually needed for n bodies
+    const int rounds = (n + 64 * SMALL_WAVES - 1) / (64 * SMALL_WAVES);
+    const int chunk = wave * (64 * rounds);
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    uint64_t k[SMALL_KPT];
+    uint32_t v[SMALL_KPT];
+    uint32_t live = 0;
+#pragma unroll
+    for (int r = 0; r < SMALL_KPT; r++) {
+        if (r >= rounds) break;
+        const int i = chunk + r * 64 + lane;
+        k[r] = KEY_DEAD;
+        v[r] = (uint32_t)i;
+        if (i < n) {
+            const R4 p = posm[i];
+            k[r] = body_key((double)p.x, (double)p.y, (double)p.z, lox, loy, loz, width);
+            live += k[r] != KEY_DEAD;
+        }
+    }
+    for (int pass = 0; pass < 8; pass++) {
+        const int shift = pass * 8;
+#pragma unroll
+        for (int w = 0; w < SMALL_WAVES / 4; w++) wcount[w * 4 + (tid >> 8)][tid & 255] = 0;
+        __syncthreads();
+        volatile uint32_t* wc = wcount[wave];
+        uint32_t rank[SMALL_KPT];
+#pragma unroll
+        for (int r = 0; r < SMALL_KPT; r++) {
+            if (r >= rounds) break;
+            const uint32_t digit = (uint32_t)(k[r] >> shift) & 255u;
+            unsigned long long peers = ~0ull;
+#pragma unroll
+            for (int b = 0; b < 8; b++) {
+                const bool bit = (digit >> b) & 1u;
+                const unsigned long long m = __ballot(bit);
+                peers &= bit ? m : ~m;
+            }
+            const uint32_t prior = wc[digit];
+            rank[r] = prior + (uint32_t)__popcll(peers & lt_mask);
+            if ((peers & lt_mask) == 0) wc[digit] = prior + (uint32_t)__popcll(peers);
+        }
+        __syncthreads();
+        // threads 0..255 own one digit each: offsets of the waves within the digit, then the digit's first slot
+        uint32_t dcount = 0;
+        if (tid < 256) {
+#pragma unroll
+            for (int w = 0; w < SMALL_WAVES; w++) { const uint32_t c = wcount[w][tid]; wcount[w][tid] = dcount; dcount += c; }
+        }
+        {
+            uint32_t inc = wave_incl_scan(dcount);
+            if (lane == 63) wsum[wave] = inc;
+            __syncthreads();
+            uint32_t base = 0;
+            for (int w = 0; w < wave; w++) base += wsum[w];
+            if (tid < 256) dbase[tid] = base + inc - dcount;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < SMALL_KPT; r++) {
+            if (r >= rounds) break;
+            const uint32_t digit = (uint32_t)(k[r] >> shift) & 255u;
+            const uint32_t slot = dbase[digit] + wcount[wave][digit] + rank[r];
+            skey[slot] = k[r];
+            sval[slot] = v[r];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < SMALL_KPT; r++) {
+            if (r >= rounds) break;
+            k[r] = skey[chunk + r * 64 + lane];
+            v[r] = sval[chunk + r * 64 + lane];
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int r = 0; r < SMALL_KPT; r++) {
+        if (r >= rounds) break;
+        const int i = chunk + r * 64 + lane;
+        if (i < n) { keys_out[i] = k[r]; idx_out[i] = v[r]; }     // padding slots sorted behind every real body
+    }
+    // live bodies
+    for (int d = 32; d >= 1; d >>= 1) live += __shfl_down(live, d, 64);
+    if (lane == 0) wsum[wave] = live;
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t tot = 0;
+        for (int w = 0; w < SMALL_WAVES; w++) tot += wsum[w];
+        counters[0] = (int)tot;
     }
 }
 
@@ -462,6 +598,28 @@ __global__ __launch_bounds__(256) void psum_apply_kernel(const R4* __restrict__ 
     }
 }
 
+// Few bodies: the three steps above in one workgroup with a running carry.  The summation order differs from the
+// tiled version only in where the carries are added, which every engine does alike for a given n.
+template <typename R4>
+__global__ __launch_bounds__(256) void psum_single_kernel(const R4* __restrict__ posm, int n, D4* __restrict__ prefix)
+{
+    D4 carry{0, 0, 0, 0};
+    for (int base0 = 0; base0 <= n; base0 += PSUM_TILE) {
+        const int base = base0 + threadIdx.x * 8;
+        D4 v[8], s{0, 0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < 8; k++) { v[k] = body_moments(posm, base + k, n); s = d4_add(s, v[k]); }
+        D4 tot;
+        D4 off = d4_add(carry, block_excl_scan_d4(s, &tot));
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            if (base + k <= n) prefix[base + k] = off;
+            off = d4_add(off, v[k]);
+        }
+        carry = d4_add(carry, tot);
+    }
+}
+
 // Writes the pre-order node array: thread t < n handles sorted leaf t, thread n + i handles binary node i.
 // cellcnt[a] = number of branching cells whose first leaf is < a (exclusive scan of popcount(lvlmask)).
 // PREFIX: cells get their mass and centre of mass here, from the prefix sums; otherwise leaves seed node_sum
@@ -564,6 +722,8 @@ static int free_ptr(void** p)
     return NBE_OK;
 }
 
+int tree_small_limit(void) { return SMALL_SORT_MAX; }
+
 int tree_workspace_reserve(nbe_engine* e)
 {
     TreeWork& w = e->tw;
@@ -624,6 +784,11 @@ static int sort_and_build_t(nbe_engine* e)
 
     if (e->timing) NBE_HIP(hipEventRecord(e->ev[0], e->stream));
     NBE_HIP(hipMemsetAsync(w.counters, 0, 4 * sizeof(int), e->stream));
+    if (n <= e->small_max) {
+        hipLaunchKernelGGL((small_sort_kernel<R4>), dim3(1), dim3(1024), 0, e->stream, force_pos, n, lox, loy, loz, W, w.keys[0],
+                           w.sidx[0], w.counters);
+        NBE_HIP(hipGetLastError());
+    } else {
     hipLaunchKernelGGL((keys_kernel<R4>), dim3(nb), dim3(256), 0, e->stream, force_pos, n, lox, loy, loz, W, w.keys[0],
                        w.sidx[0], w.counters);
     NBE_HIP(hipGetLastError());
@@ -641,6 +806,7 @@ static int sort_and_build_t(nbe_engine* e)
                            w.keys[in ^ 1], w.sidx[in ^ 1], w.block_hist, n, shift, nblocks);
         NBE_HIP(hipGetLastError());
         in ^= 1;
+    }
     }
     NBE_TRY(frame_stream_guard_write(e, nxt));
     hipLaunchKernelGGL((permute_kernel<S4>), dim3(nb), dim3(256), 0, e->stream, w.sidx[0], n, (const S4*)e->posm[cur],
@@ -664,10 +830,14 @@ static int sort_and_build_t(nbe_engine* e)
     constexpr bool PREFIX = !__is_same(NodeT, NodeD);
     if (PREFIX) {
         const unsigned tiles = cdiv((size_t)n + 1, PSUM_TILE);
-        hipLaunchKernelGGL((psum_reduce_kernel<R4>), dim3(tiles), dim3(256), 0, e->stream, sorted_pos, n, (D4*)w.prefix_tiles);
-        hipLaunchKernelGGL(psum_scan_sums_kernel, dim3(1), dim3(256), 0, e->stream, (D4*)w.prefix_tiles, (int)tiles);
-        hipLaunchKernelGGL((psum_apply_kernel<R4>), dim3(tiles), dim3(256), 0, e->stream, sorted_pos, n,
-                           (const D4*)w.prefix_tiles, (D4*)w.prefix);
+        if (n <= e->small_max) {
+            hipLaunchKernelGGL((psum_single_kernel<R4>), dim3(1), dim3(256), 0, e->stream, sorted_pos, n, (D4*)w.prefix);
+        } else {
+            hipLaunchKernelGGL((psum_reduce_kernel<R4>), dim3(tiles), dim3(256), 0, e->stream, sorted_pos, n, (D4*)w.prefix_tiles);
+            hipLaunchKernelGGL(psum_scan_sums_kernel, dim3(1), dim3(256), 0, e->stream, (D4*)w.prefix_tiles, (int)tiles);
+            hipLaunchKernelGGL((psum_apply_kernel<R4>), dim3(tiles), dim3(256), 0, e->stream, sorted_pos, n,
+                               (const D4*)w.prefix_tiles, (D4*)w.prefix);
+        }
         NBE_HIP(hipGetLastError());
     }
     hipLaunchKernelGGL((emit_nodes_kernel<R4, NodeT, PREFIX>), dim3(cdiv(2 * (size_t)n, 256)), dim3(256), 0, e->stream, n,

@@ -95,6 +95,18 @@ __global__ __launch_bounds__(WALK_BLOCK) void walk_kernel(
     const unsigned nwg = gridDim.x, q8 = nwg / 8, r8 = nwg % 8, xcd = blockIdx.x % 8;
     const unsigned wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + blockIdx.x / 8;
     const int ibase = t0 + (int)wg * (WALK_BLOCK * NS) + threadIdx.x;
+    if (OUT == OUT_FUSED) {
+        // bodies past n_alive (removed by the bound check) move to the next buffer unchanged
+#pragma unroll
+        for (int s = 0; s < NS; s++) {
+            const int i = ibase + s * WALK_BLOCK;
+            if (i >= tend && i < t1) {
+                pos_out[i] = pos_in[i];
+                vel_out[i] = vel_in[i];
+                if (mirror_out) { const A4 p = pos_in[i]; mirror_out[i] = make_float4((float)p.x, (float)p.y, (float)p.z, (float)p.w); }
+            }
+        }
+    }
     if (__ballot(ibase < tend) == 0) return;     // whole wave past the end (group 0 holds its lowest bodies)
 
     bool valid[NS];
@@ -185,22 +197,6 @@ __global__ __launch_bounds__(WALK_BLOCK) void walk_kernel(
     }
 }
 
-// Bodies past n_alive (removed by the bound check) are carried along unchanged when the state moves to the
-// next buffer.
-template <typename S4>
-__global__ __launch_bounds__(256) void carry_dead_kernel(const int* __restrict__ counters, int t0, int t1,
-                                                         const S4* __restrict__ pos_in, const S4* __restrict__ vel_in,
-                                                         const float4* __restrict__ mirror_in, S4* __restrict__ pos_out,
-                                                         S4* __restrict__ vel_out, float4* __restrict__ mirror_out)
-{
-    const int na = counters[0];
-    const int i = t0 + blockIdx.x * 256 + threadIdx.x;
-    if (i >= t1 || i < na) return;
-    pos_out[i] = pos_in[i];
-    vel_out[i] = vel_in[i];
-    if (mirror_in) mirror_out[i] = mirror_in[i];
-}
-
 #ifndef WALK_NS
 #define WALK_NS 1
 #endif
@@ -226,13 +222,10 @@ static int launch_walk(nbe_engine* e, const void* src, uint64_t t0, uint64_t t1,
     A4* vel_out = (A4*)e->vel[dst_buf];
     float4* mirror_out = mixed ? e->mirror[dst_buf] : nullptr;
     dim3 grid(cdiv(nt, WALK_BLOCK * WALK_NS));
-    dim3 cgrid(cdiv(nt, 256));
     if (fused) {
         WALK_LAUNCH(OUT_FUSED, false) grid, dim3(WALK_BLOCK), 0, e->stream, (const NodeT*)e->tw.nodes,
                            e->tw.counters, (const R4*)src, (int)t0, (int)t1, (R)e->cfg.theta, floor2, G, dt, (A4*)e->acc,
                            pos_in, vel_in, pos_out, vel_out, mirror_out, e->tw.d_interactions);
-        hipLaunchKernelGGL((carry_dead_kernel<A4>), cgrid, dim3(256), 0, e->stream, e->tw.counters, (int)t0, (int)t1, pos_in,
-                           vel_in, mixed ? e->mirror[src_buf] : (const float4*)nullptr, pos_out, vel_out, mirror_out);
     } else if (count) {
         NBE_HIP(hipMemsetAsync(e->tw.d_interactions, 0, 8 * sizeof(unsigned long long), e->stream));
         WALK_LAUNCH(OUT_ACC, true) grid, dim3(WALK_BLOCK), 0, e->stream, (const NodeT*)e->tw.nodes,

@@ -259,3 +259,30 @@ def test_1m_plummer_properties(gpu):
     sample = np.arange(0, n, 997)
     check(acc[sample], ref[sample], "f32")
     assert abs(int(st.interactions) - ost.interactions) <= 1e-4 * ost.interactions
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 1000, 1024, 1025, 5000, 8191, 8192])
+@pytest.mark.parametrize("precision", ["f32", "f64"])
+def test_single_workgroup_sort_equals_tiled_sort(gpu, monkeypatch, n, precision):
+    """Up to 8192 bodies the keys, the sort and the scans run in one workgroup each; the tiled kernels used above
+    that size must give the same tree and the same accelerations bit for bit (NBODY_SMALL_TREE_MAX=0 forces them)."""
+    rng = np.random.default_rng(n)
+    pos = rng.uniform(-3e4, 3e4, (n, 3)); mass = np.abs(rng.normal(1e4, 3e3, n)) + 1
+    if n > 10:
+        pos[3] = pos[7]                      # a bucket of equal keys
+        pos[5] = [4e4, 0, 0]                 # outside the bound
+    out = []
+    for knob in (None, "0"):
+        if knob is None:
+            monkeypatch.delenv("NBODY_SMALL_TREE_MAX", raising=False)
+        else:
+            monkeypatch.setenv("NBODY_SMALL_TREE_MAX", knob)
+        with Engine(mode="tree", precision=precision, theta=0.6) as e:
+            e.upload(pos, np.zeros_like(pos), mass)
+            acc, alive = e.accel()
+            nodes = e.tree_nodes()
+            e.step(2)
+            p, v, m, ids = e.download()
+        out.append((acc, alive, nodes, p, v, ids))
+    for a, b in zip(out[0], out[1]):
+        assert np.array_equal(a, b, equal_nan=True)
