@@ -239,6 +239,34 @@ def main():
             extra["default_scene_1002_tree_theta1"]["cpu_port_ms_per_step"] = 1e3 * (time.perf_counter() - t0) / 100
             extra["default_scene_1002_tree_theta1"]["cpu_port_note"] = "C port of main.go:129-178 as written: serial build, 4 walk threads, reference COM update, last N mod 4 bodies unwalked"
 
+    if not args.no_extra and world == 1:
+        # benchmark configuration 5 rehearsed on one GPU at 1/16 size: two galaxies on the reference's approach course
+        # (main.go:35-36), fp32 pair terms with fp64 sums and an fp64 integrator, softened, with the drift it is judged by
+        gp = physics.galaxy_pair(1 << 19, seed=1)
+        e6 = Engine(mode="tree", precision="mixed", theta=0.5, eps=1.0, device=local)
+        e6.upload(gp.pos, gp.vel, gp.mass)
+        e6.set_stream(torch.cuda.current_stream().cuda_stream)
+        ke0, pe0, p0 = e6.energy()
+        s6 = timed_steps(lambda: e6.step(1), sync, barrier, 0, 50)
+        ke1, pe1, p1 = e6.energy()
+        pscale = float(np.sum(gp.mass[:, None] * np.abs(gp.vel)))
+        extra["galaxy_pair_2x512k_bh_mixed_eps1"] = {
+            "ms_per_step": 1e3 * s6 / 50, "steps": 50,
+            "energy_drift_rel": abs((ke1 + pe1) - (ke0 + pe0)) / abs(ke0 + pe0),
+            "momentum_drift_rel": float(np.abs(p1 - p0).max()) / pscale,
+            "note": "potential summed over the nodes the walk accepts (theta 0.5) at both ends"}
+        e6.close()
+        # the 1M-body step with collisions on (radius 2 m, physics.go:20): search, queue, merge and update after the walk
+        pl = physics.plummer(1 << 20, seed=1)
+        e7 = Engine(mode="tree", precision="f32", theta=0.5, collisions=True, device=local)
+        e7.upload(pl.pos, pl.vel, pl.mass)
+        e7.set_stream(torch.cuda.current_stream().cuda_stream)
+        s7 = timed_steps(lambda: e7.step(1), sync, barrier, 2, 20)
+        st7 = e7.stats()
+        extra["bh_theta0.5_fp32_plummer_1M_collisions_on"] = {"ms_per_step": 1e3 * s7 / 20, "merges_in_22_steps": int(st7.merges),
+                                                             "bodies_left": int(st7.n_alive)}
+        e7.close()
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline_direct(args.cpu_sample) if headline_mode == "direct" else None
