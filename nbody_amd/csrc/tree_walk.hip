@@ -69,11 +69,22 @@ __device__ __forceinline__ bool node_opens(const RawD& nd, double r2, double the
 // NS: independent traversals (groups of 64 bodies) interleaved in one wave, each with its own cursor, node
 // registers and sit-out index; a group that finishes first parks on the sentinel record behind the last node
 // (mass 0, skip = itself).  Measured at 1M / 4M bodies: NS = 1: 2.21 / 8.53 ms, NS = 2: 2.31 / 8.21 ms,
-// NS = 3: 3.0 / 9.5 ms, so NS = 1 ships.  What bounds the kernel (rocprofv3 counters, 1M-body Plummer sphere,
-// theta = 0.5): 6.5e7 node visits per pass, one 32-byte scalar load each; the scalar data cache serves only
-// 29 % of them (SQC_DCACHE_HITS / REQ), the rest go to L2 (97 % hits after the XCD remap below), and waves sit
-// in s_waitcnt for 47 % of their cycles even at 8 waves per SIMD: the limit is the scalar cache's miss
-// throughput, not arithmetic (16 VALU + 8 SALU instructions per visit) and not HBM.
+// NS = 3: 3.0 / 9.5 ms, so NS = 1 ships.
+//
+// What bounds the kernel (rocprofv3 counters and an instrumented build; 1M-body Plummer sphere, theta = 0.5):
+// 6.2e7 node visits per pass (3,780 per wave, standard deviation 14 %), each 17 vector + 7 scalar instructions and
+// one 32-byte scalar load.  Most vector instructions read the node from scalar registers, which halves their
+// rate: about 58 issue cycles per visit against 78 cycles measured per visit and SIMD, so the vector ALU is busy
+// three quarters of the time; the scalar cache serves only 29 % of the node loads (L2 serves 97 % of the rest
+// after the XCD remap), and eight waves per SIMD hide most of that latency.  Consequently neither the workgroup
+// size (64 .. 1024 threads: 2.16 .. 2.31 ms) nor a second traversal per wave nor prefetching both successors of
+// a node helps, and every scalar instruction removed from the loop does (five fewer: -4 %).
+// The visits are not equally useful: in 84 % nobody opens the node, in 5 % nobody takes it, and in 27 % at most 8
+// of the 64 lanes are awake (deep in the near field of a few bodies while the rest of the wave sits out).
+// Tried: handing subtrees that at most 16 lanes open to those lanes for private walks with vector loads after
+// the shared walk.  It removes 31 % of the shared visits, but a private step (two vector loads with up to 64
+// different addresses) costs three shared visits and the remaining shared visits are the cache-unfriendly ones:
+// 2.04 ms against 2.07 ms, not worth its complexity.
 template <typename R, typename A, typename NodeT, int OUT, bool COUNT, bool SOFT, int NS>
 __global__ __launch_bounds__(WALK_BLOCK) void walk_kernel(
     const NodeT* __restrict__ nodes, const int* __restrict__ counters, const typename V4<R>::type* __restrict__ posm,
