@@ -7,9 +7,8 @@
 //   frame loop      main.go:80-190  (frames+1 iterations; a frame copy goes to the workers BEFORE each step)
 //   output workers  main.go:50-61   4 consumers behind a queue of capacity 32 (here fed by nbe_frame_stream_begin)
 //   save / resume   main.go:199-248 (own little-endian binary format; the reference's gob files need Go)
-// The step itself (main.go:104-178) is one nbe_step call.  Collisions run on the GPU in tree mode (the search,
-// queue and merge of tree.go:245-281, main.go:151-167); the direct sum insists on -nocollision, because the
-// engine does not reproduce the order-dependent merge inside the pair loop (main.go:122-126).
+// The step itself (main.go:104-178) is one nbe_step call, collisions included: in tree mode the search, queue and
+// merge of tree.go:245-281 / main.go:151-167, in the direct sum the merge inside the pair sweep (main.go:122-126).
 // The reference's sinks are a PNG renderer, a gob chunk store and sqlite; the sink here writes the record the
 // gob store keeps per body (gob.go:54-61: X, Y, Z, Mass, Radius as float32, keyed by ID) as raw binary frames.
 #include <chrono>
@@ -254,7 +253,6 @@ int main(int argc, char** argv)
         else if (a == "-nocollision") nocollision = true;
         else panic("flag provided but not defined: " + a);
     }
-    if (!nocollision && !tree) panic("collisions need -tree on the GPU engine: run the direct sum with -nocollision");
 
     const int dt = 60 * 60;                                  // main.go:28
     const int iterPerFrame = 1;                              // main.go:29

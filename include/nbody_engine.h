@@ -49,7 +49,7 @@ typedef struct {
     double bound_width;     /* edge of the cubic simulation bound; bodies outside are removed in tree mode */
     int device;             /* HIP device ordinal */
     int collisions;         /* 0 = the `-nocollision` run (main.go:24); 1 = bodies that touch merge (tree mode:
-                               tree.go:245-281 + main.go:151-167 + physics.go:153-162) */
+                               tree.go:245-281 + main.go:151-167; direct sum: main.go:122-126; physics.go:153-162) */
 } nbe_config;
 
 typedef struct {
@@ -61,7 +61,8 @@ typedef struct {
     uint64_t tree_nodes;        /* leaves + branching cells of the last build */
     uint64_t tree_cells;        /* branching cells of the last build */
     uint64_t merges;            /* bodies absorbed by collisions since upload (physics.go:153-162) */
-    uint64_t collision_pairs;   /* pairs queued by the collision search of the last step (main.go:153-159) */
+    uint64_t collision_pairs;   /* tree: pairs queued by the collision search of the last step (main.go:153-159);
+                                   direct sum: merges of the last step */
     float ms_sort, ms_build, ms_force, ms_total;   /* device time of the last timed step (nbe_step_timed) */
 } nbe_stats_t;
 
@@ -113,7 +114,9 @@ int nbe_accel(nbe_engine *e, double *acc_xyz, uint8_t *alive_out);
  * With collisions on (tree mode) a step is: force pass, collision search of every live body through the tree in
  * upload order (tree.go:245-281, reproducing its pruning rules as written), the queued pairs merged one after
  * the other in queue order (main.go:160-166, physics.go:153-162), then the update; an absorbed body leaves the
- * simulation like one that left the bound.  Such a step reads the queue length back and so synchronises. */
+ * simulation like one that left the bound.  Such a step reads the queue length back and so synchronises.
+ * With collisions on in the direct sum, every step first tests all pairs for contact; a step with a touching pair
+ * is replayed as the reference's i < j sweep with merges on the spot (main.go:107-128), the others run fused. */
 int nbe_step(nbe_engine *e, int nsteps);
 
 /* One step bracketed by device events; fills stats->ms_* (synchronises). */

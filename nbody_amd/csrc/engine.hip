@@ -65,10 +65,6 @@ extern "C" int nbe_create(const nbe_config* cfg, nbe_engine** out)
     if (cfg->precision < NBE_PREC_F32 || cfg->precision > NBE_PREC_F64) { nbe_set_error("bad precision %d", cfg->precision); return NBE_E_INVALID; }
     if (!(cfg->bound_width > 0) || !(cfg->theta >= 0) || !(cfg->eps >= 0)) { nbe_set_error("bound_width must be > 0, theta and eps >= 0"); return NBE_E_INVALID; }
     if (cfg->collisions != 0 && cfg->collisions != 1) { nbe_set_error("collisions must be 0 or 1"); return NBE_E_INVALID; }
-    if (cfg->collisions && cfg->mode != NBE_MODE_TREE) {
-        nbe_set_error("collisions are implemented for tree mode only (main.go:151-167); run the direct sum with collisions = 0");
-        return NBE_E_UNSUPPORTED;
-    }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
         nbe_set_error("no HIP device available (this library has no CPU path)");
@@ -107,6 +103,7 @@ extern "C" void nbe_destroy(nbe_engine* e)
     (void)hipStreamSynchronize(e->stream);
     (void)free_state(e);
     (void)collide_workspace_free(e);
+    (void)direct_collide_free(e);
     TreeWork& w = e->tw;
     void* ptrs[] = {w.keys[0], w.keys[1], w.sidx[0], w.sidx[1], w.block_hist, w.scan_tmp, w.bt_first, w.bt_last, w.bt_parent,
                     w.bt_level, w.lvlmask, w.cellcnt, w.nodes, w.node_level, w.node_sum, w.counters, w.d_interactions,
@@ -193,8 +190,14 @@ extern "C" int nbe_upload(nbe_engine* e, size_t n, const double* pos, const doub
     if (e->cfg.collisions) {
         NBE_TRY(collide_workspace_reserve(e));
         NBE_TRY(collide_fill_radius(e, e->radius[0], 2.0));      // physics.go:20 defaultRadius
-        NBE_HIP(hipMemsetAsync(e->tw.counters, 0, 16 * sizeof(int), e->stream));
         NBE_HIP(hipMemsetAsync(e->cw.dead, 0, n, e->stream));
+        if (e->cfg.mode == NBE_MODE_TREE) {
+            NBE_HIP(hipMemsetAsync(e->tw.counters, 0, 16 * sizeof(int), e->stream));
+        } else {
+            NBE_TRY(direct_collide_reserve(e));
+            NBE_HIP(hipMemsetAsync(e->dc_counters, 0, 8 * sizeof(int), e->stream));
+            e->direct_absorbed = 0;
+        }
     }
     return NBE_OK;
 }
@@ -217,6 +220,10 @@ static int read_counts(nbe_engine* e, size_t* slots)
         e->stats.tree_cells = (uint64_t)c[2];
         e->stats.merges = (uint64_t)c[6];
     }
+    if (e->cfg.collisions && e->cfg.mode == NBE_MODE_DIRECT) {
+        absorbed = e->direct_absorbed;
+        e->stats.merges = e->direct_absorbed;
+    }
     e->host_nalive = *n_alive - absorbed;
     e->stats.n_alive = *n_alive - absorbed;
     return NBE_OK;
@@ -226,12 +233,15 @@ static int read_counts(nbe_engine* e, size_t* slots)
 static int read_dead(nbe_engine* e, size_t slots, std::vector<uint8_t>* dead)
 {
     dead->assign(slots, 0);
-    if (e->cfg.collisions && e->have_counts && slots > 0) {
+    if (e->cfg.collisions && (e->have_counts || e->cfg.mode == NBE_MODE_DIRECT) && slots > 0) {
         NBE_HIP(hipMemcpyAsync(dead->data(), e->cw.dead, slots, hipMemcpyDeviceToHost, e->stream));
         NBE_HIP(hipStreamSynchronize(e->stream));
     }
     return NBE_OK;
 }
+
+// Radii follow the state buffers in tree mode (they are reordered with it); the direct sum never reorders.
+static double* radius_buf(nbe_engine* e) { return e->cfg.mode == NBE_MODE_TREE ? e->radius[e->cur] : e->radius[0]; }
 
 // upload index -> device slot of every live body (0xffffffff for removed ones).
 static int live_slots(nbe_engine* e, std::vector<uint32_t>* slot_of, size_t* n_alive)
@@ -307,7 +317,7 @@ extern "C" int nbe_set_radius(nbe_engine* e, const double* radius)
     NBE_HIP(hipStreamSynchronize(e->stream));
     std::vector<double> dev(n);
     for (size_t d = 0; d < n; d++) dev[d] = radius[horig[d]];
-    NBE_HIP(hipMemcpy(e->radius[e->cur], dev.data(), n * sizeof(double), hipMemcpyHostToDevice));
+    NBE_HIP(hipMemcpy(radius_buf(e), dev.data(), n * sizeof(double), hipMemcpyHostToDevice));
     return NBE_OK;
 }
 
@@ -323,7 +333,7 @@ extern "C" int nbe_get_radius(nbe_engine* e, double* radius, size_t* n_alive_out
     if (n_alive_out) *n_alive_out = na;
     if (n == 0 || !radius) return NBE_OK;
     std::vector<double> dev(n);
-    NBE_HIP(hipMemcpyAsync(dev.data(), e->radius[e->cur], n * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    NBE_HIP(hipMemcpyAsync(dev.data(), radius_buf(e), n * sizeof(double), hipMemcpyDeviceToHost, e->stream));
     NBE_HIP(hipStreamSynchronize(e->stream));
     size_t k = 0;
     for (size_t u = 0; u < n; u++)
@@ -435,7 +445,12 @@ static int step_once_full(nbe_engine* e)
         if (e->cfg.mode == NBE_MODE_TREE) NBE_TRY(force_pass(e, 0, e->n, false, true));
         NBE_HIP(hipEventRecord(e->ev[4], e->stream));
     }
-    if (e->cfg.collisions) {
+    if (e->cfg.collisions && e->cfg.mode == NBE_MODE_DIRECT) {
+        // a step with a touching pair is replayed in the reference's order of events; any other is the fused step
+        bool replayed = false;
+        NBE_TRY(direct_collide_step(e, &replayed));
+        if (!replayed) NBE_TRY(force_pass(e, 0, e->n, true));
+    } else if (e->cfg.collisions) {
         // accelerations first (the collision merge needs them apart from the update), then search, merge, update
         NBE_TRY(force_pass(e, 0, e->n, false));
         NBE_TRY(collide_and_update(e));

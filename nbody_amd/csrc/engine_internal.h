@@ -107,6 +107,7 @@ struct FrameSlot {
     float* xyzm = nullptr;        // pinned, n x 4 floats
     uint32_t* orig = nullptr;     // pinned, n x u32 (device order -> upload index)
     float* radius = nullptr;      // pinned, n floats (collisions on)
+    uint8_t* dead = nullptr;      // pinned, n flags (direct mode with collisions on)
     int* n_alive = nullptr;       // pinned scalar
     int* d_n_alive = nullptr;     // device snapshot of the live count, taken on the compute stream
     hipEvent_t done = nullptr;    // copy finished (side stream)
@@ -147,6 +148,12 @@ struct nbe_engine {
     uint32_t* orig[2] = {nullptr, nullptr};   // device order -> upload index; flips only when the state is sorted
     double* radius[2] = {nullptr, nullptr};   // collisions on: body radii, indexed like posm (follows `cur`)
     CollWork cw;
+    // direct mode with collisions on (direct_collide.hip); radii and absorbed flags are not reordered there, so
+    // radius[0] and cw.dead are the only copies
+    double4* dc_force = nullptr;    // per body: force accumulator of the replayed sweep
+    int* dc_counters = nullptr;     // [0] some pair touches, [1] bodies absorbed since upload
+    size_t dc_cap = 0;
+    size_t direct_absorbed = 0;     // host copy of dc_counters[1]
     int orig_cur = 0;
     int cur = 0;
     int small_max = 0;              // tree mode: up to this many bodies take the single-workgroup sort and scans
@@ -185,6 +192,10 @@ int collide_workspace_free(nbe_engine* e);
 int collide_fill_radius(nbe_engine* e, double* dst, double value);
 int collide_emit_nodes(nbe_engine* e);          // after the build: geometry records for the collision search
 int collide_and_update(nbe_engine* e);          // search + merge + update of the state in e->cur into e->cur^1
+// direct_collide.hip
+int direct_collide_reserve(nbe_engine* e);
+int direct_collide_free(nbe_engine* e);
+int direct_collide_step(nbe_engine* e, bool* replayed);
 // energy.hip
 int energy_compute(nbe_engine* e, double* ke, double* pe, double mom[3]);
 // frames.hip

@@ -35,7 +35,20 @@ static void delivery_loop(nbe_engine* e)
         const int na_raw = *s.n_alive;               // -1: no tree build has removed anything yet
         size_t na = na_raw < 0 ? e->n : (size_t)na_raw;
         if (na > e->n) na = e->n;
-        if (e->cfg.collisions) {
+        if (e->cfg.collisions && e->cfg.mode == NBE_MODE_DIRECT) {
+            // direct sum: absorbed bodies stay in the arrays and are flagged; leave them out (main.go:91-95)
+            size_t k = 0;
+            for (size_t d = 0; d < na; d++) {
+                if (s.dead[d]) continue;
+                if (k != d) {
+                    for (int c = 0; c < 4; c++) s.xyzm[4 * k + c] = s.xyzm[4 * d + c];
+                    s.radius[k] = s.radius[d];
+                    s.orig[k] = s.orig[d];
+                }
+                k++;
+            }
+            na = k;
+        } else if (e->cfg.collisions) {
             // bodies absorbed by a collision since the last build are parked outside the bound without mass:
             // leave them out, as the nil check at main.go:91-95 does
             const double W = e->cfg.bound_width;
@@ -88,6 +101,7 @@ extern "C" int nbe_frame_stream_begin(nbe_engine* e, int every, int slots, int f
         NBE_HIP(hipHostMalloc((void**)&s.xyzm, cap * 4 * sizeof(float), hipHostMallocDefault));
         NBE_HIP(hipHostMalloc((void**)&s.orig, cap * sizeof(uint32_t), hipHostMallocDefault));
         if (e->cfg.collisions) NBE_HIP(hipHostMalloc((void**)&s.radius, cap * sizeof(float), hipHostMallocDefault));
+        if (e->cfg.collisions && e->cfg.mode == NBE_MODE_DIRECT) NBE_HIP(hipHostMalloc((void**)&s.dead, cap, hipHostMallocDefault));
         NBE_HIP(hipHostMalloc((void**)&s.n_alive, sizeof(int), hipHostMallocDefault));
         NBE_HIP(hipMalloc((void**)&s.d_n_alive, sizeof(int)));
         NBE_HIP(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
@@ -147,8 +161,12 @@ int frame_stream_before_step(nbe_engine* e)
     NBE_HIP(hipMemcpyAsync(s.orig, e->orig[e->orig_cur], n * sizeof(uint32_t), hipMemcpyDeviceToHost, fs.side));
     if (e->cfg.collisions) {
         // the radii live beside the state buffer and are rewritten together with it, so the same guard covers them
-        hipLaunchKernelGGL(narrow_radius_kernel, dim3(cdiv(n, 256)), dim3(256), 0, fs.side, (const double*)e->radius[e->cur],
-                           fs.radius_staging, (int)n);
+        const bool direct = e->cfg.mode == NBE_MODE_DIRECT;
+        hipLaunchKernelGGL(narrow_radius_kernel, dim3(cdiv(n, 256)), dim3(256), 0, fs.side,
+                           (const double*)(direct ? e->radius[0] : e->radius[e->cur]), fs.radius_staging, (int)n);
+        // direct sum: radii and flags are single arrays that only a replayed step writes; that step waits for this
+        // copy through the guard on the state buffer it writes next
+        if (direct) NBE_HIP(hipMemcpyAsync(s.dead, e->cw.dead, n, hipMemcpyDeviceToHost, fs.side));
         NBE_HIP(hipGetLastError());
         NBE_HIP(hipMemcpyAsync(s.radius, fs.radius_staging, n * sizeof(float), hipMemcpyDeviceToHost, fs.side));
     }
@@ -181,6 +199,7 @@ int frame_stream_stop(nbe_engine* e)
         if (s.xyzm) (void)hipHostFree(s.xyzm);
         if (s.orig) (void)hipHostFree(s.orig);
         if (s.radius) (void)hipHostFree(s.radius);
+        if (s.dead) (void)hipHostFree(s.dead);
         if (s.n_alive) (void)hipHostFree(s.n_alive);
         if (s.d_n_alive) (void)hipFree(s.d_n_alive);
         if (s.done) (void)hipEventDestroy(s.done);

@@ -51,9 +51,6 @@ def test_create_rejects_bad_arguments():
     cfg.mode = 7
     assert lib.nbe_create(C.byref(cfg), C.byref(h)) == -1 and not h.value
     cfg.mode = 0
-    cfg.collisions = 1      # collisions exist in tree mode only
-    assert lib.nbe_create(C.byref(cfg), C.byref(h)) == -4 and not h.value
-    assert b"tree mode" in lib.nbe_last_error()
     cfg.collisions = 2
     assert lib.nbe_create(C.byref(cfg), C.byref(h)) == -1 and not h.value
     cfg.collisions = 0

@@ -203,8 +203,6 @@ def test_accel_and_energy_after_merges(gpu):
 
 
 def test_unsupported_combinations_fail_loudly(gpu):
-    with pytest.raises(EngineError, match="tree mode"):
-        Engine(mode="direct", collisions=True)
     pos, vel, mass, rad = crowd(100, 20.0, 1)
     with Engine(mode="tree", collisions=True) as e:
         e.upload(pos, vel, mass)
@@ -217,3 +215,110 @@ def test_unsupported_combinations_fail_loudly(gpu):
         e.upload(pos, vel, mass)
         with pytest.raises(EngineError, match="collisions on"):
             e.set_radius(rad)
+
+
+# ---- collisions inside the direct pair sweep (main.go:107-128) ----------------------------------------------------
+OKD = dict(mode="direct")
+
+
+def run_direct(pos, vel, mass, rad, nsteps, precision="f64", **kw):
+    with Engine(mode="direct", precision=precision, collisions=True, **kw) as e:
+        e.upload(pos, vel, mass)
+        if rad is not None:
+            e.set_radius(rad)
+        per_step = []
+        for _ in range(nsteps):
+            e.step(1)
+            st = e.stats()
+            per_step.append((int(st.merges), int(st.n_alive)))
+        p, v, m, ids = e.download()
+        r = e.get_radius()
+    return p, v, m, ids, r, per_step
+
+
+@pytest.mark.parametrize("seed,n,half", [(1, 600, 30.0), (2, 2000, 60.0), (3, 50, 6.0)])
+def test_direct_sweep_with_merges_matches_the_oracle(gpu, seed, n, half):
+    """One step with many merges: survivors, masses, radii, velocities and positions, including the reference's
+    habit of keeping the force terms a body collected before it grew (physics.go:136 uses the mass of the moment)."""
+    pos, vel, mass, rad = crowd(n, half, seed)
+    p, v, m, ids, r, per_step = run_direct(pos, vel, mass, rad, 1, dt=100.0)
+    om, orad, op, ov, oalive, st = O.step_collide(mass, rad, pos, vel, nsteps=1, dt=100.0, **OKD)
+    live = oalive == 1
+    assert st.merges > 3 and per_step[0] == (st.merges, int(live.sum()))
+    assert np.array_equal(ids, np.nonzero(live)[0].astype(np.uint64))
+    assert np.abs(m - om[live]).max() <= 1e-12 * om.max()
+    assert np.abs(r - orad[live]).max() <= 1e-13 * orad.max()
+    assert np.abs(v - ov[live]).max() <= 1e-10 * np.abs(ov[live]).max()
+    assert np.abs(p - op[live]).max() <= 1e-12 * np.abs(op[live]).max()
+
+
+def test_direct_many_steps_mix_replayed_and_fused_steps(gpu):
+    """30 steps of a scene in which only some steps have a touching pair: those are replayed in the reference's
+    order of events, the others run the fused kernel; merges so far and survivors agree after every step."""
+    pos, vel, mass, rad = crowd(400, 120.0, 21, rmin=0.5, rmax=2.0)
+    vel = vel * 30.0
+    nsteps = 30
+    p, v, m, ids, r, per_step = run_direct(pos, vel, mass, rad, nsteps, dt=60.0)
+    om, orad, op, ov, oalive = mass, rad, pos, vel, None
+    merges, steps_with_merge = 0, 0
+    for s in range(nsteps):
+        om, orad, op, ov, oalive, st = O.step_collide(om, orad, op, ov, nsteps=1, alive=oalive, dt=60.0, **OKD)
+        merges += st.merges
+        steps_with_merge += st.merges > 0
+        assert per_step[s] == (merges, int(oalive.sum())), f"step {s}"
+    assert 0 < steps_with_merge < nsteps
+    live = oalive == 1
+    assert np.array_equal(ids, np.nonzero(live)[0].astype(np.uint64))
+    assert np.abs(m - om[live]).max() <= 1e-12 * om.max()
+    assert np.abs(p - op[live]).max() <= 1e-9 * np.abs(op[live]).max()
+    assert np.abs(v - ov[live]).max() <= 1e-8 * np.abs(ov[live]).max()
+
+
+def test_direct_row_order_and_growing_radius(gpu):
+    """Body 0 touches body 2 only after it has absorbed body 1 and grown (main.go:123 uses the radius of the moment);
+    body 3 touches body 1 where it was, but body 1 is gone by the time row 3 comes up."""
+    pos = np.array([[0.0, 0, 0], [1.5, 0, 0], [-2.2, 0, 0], [3.4, 0, 0], [500.0, 0, 0]])
+    rad = np.array([1.0, 1.0, 1.0, 1.0, 1.0])
+    mass = np.array([8.0, 8.0, 1.0, 1.0, 1.0]); vel = np.zeros((5, 3))
+    p, v, m, ids, r, per_step = run_direct(pos, vel, mass, rad, 1, dt=1e-3, G=0.0)
+    om, orad, op, ov, oalive, st = O.step_collide(mass, rad, pos, vel, nsteps=1, dt=1e-3, **OKD)
+    assert list(oalive) == [1, 0, 0, 1, 1] and st.merges == 2          # 0 absorbs 1, grows to 2^(1/3) = 1.26, then reaches 2 at 2.2 <= 2.26
+    assert list(ids) == [0, 3, 4] and per_step[0] == (2, 3)
+    assert m[0] == 17.0 and abs(r[0] - 3.0 ** (1.0 / 3.0)) < 1e-15
+
+
+@pytest.mark.parametrize("precision", ["f32", "mixed"])
+def test_direct_collisions_with_fp32_state(gpu, precision):
+    pos, vel, mass, rad = crowd(1500, 50.0, 9)
+    pos, vel, mass = f32(pos), f32(vel), f32(mass)
+    p, v, m, ids, r, per_step = run_direct(pos, vel, mass, rad, 1, precision=precision, dt=100.0)
+    om, orad, op, ov, oalive, st = O.step_collide(mass, rad, pos, vel, nsteps=1, dt=100.0, **OKD)
+    live = oalive == 1
+    assert per_step[0] == (st.merges, int(live.sum())) and st.merges > 3
+    assert np.array_equal(ids, np.nonzero(live)[0].astype(np.uint64))
+    assert np.abs(m - om[live]).max() <= 2e-7 * om.max()
+    assert np.abs(p - op[live]).max() <= 1e-6 * np.abs(op[live]).max()
+    assert np.abs(v - ov[live]).max() <= 5e-6 * np.abs(ov[live]).max()
+
+
+def test_direct_frames_and_energy_leave_out_absorbed_bodies(gpu):
+    pos, vel, mass, rad = crowd(500, 25.0, 14)
+    got = []
+    with Engine(mode="direct", precision="f64", collisions=True, dt=30.0) as e:
+        e.upload(pos, vel, mass)
+        e.set_radius(rad)
+        e.frame_stream_begin(lambda f, xyzm, ids, radius: got.append((f, xyzm, ids, radius)), every=1, slots=3)
+        e.step(5)
+        e.frame_stream_end()
+        ke, pe, mom = e.energy()
+        st = e.stats()
+    om, orad, op, ov, oalive = mass, rad, pos, vel, None
+    for s in range(5):
+        f, xyzm, ids, radius = got[s]
+        live = np.ones(len(mass), bool) if oalive is None else oalive == 1
+        assert np.array_equal(ids, np.nonzero(live)[0].astype(np.uint64)), f"frame {s}"
+        assert np.allclose(xyzm[:, 3], om[live], rtol=1e-6) and np.allclose(radius, orad[live], rtol=1e-6)
+        om, orad, op, ov, oalive, _ = O.step_collide(om, orad, op, ov, nsteps=1, alive=oalive, dt=30.0, **OKD)
+    assert int(st.n_alive) == int(oalive.sum()) < 500
+    oke, ope, omom = O.energy(om, op, ov, alive=oalive)
+    assert abs(ke - oke) <= 1e-9 * abs(oke) and abs(pe - ope) <= 1e-9 * abs(ope)

@@ -22,10 +22,8 @@ def read_frame(path):
     return rec
 
 
-def test_host_builds_and_the_direct_sum_insists_on_nocollision(tmp_path):
+def test_host_builds_and_rejects_unknown_flags(tmp_path):
     assert os.path.exists(BIN), "build it with `make -C host` (or __graft_entry__.build())"
-    r = run(["-n", "10", "-y", "0.001"], tmp_path)          # collisions exist in tree mode only
-    assert r.returncode == 2 and b"-nocollision" in r.stdout
     r = run(["-bogus"], tmp_path)
     assert r.returncode == 2 and b"flag provided but not defined" in r.stdout
 
@@ -83,3 +81,16 @@ def test_host_tree_run_with_collisions(gpu, tmp_path):
     assert abs(float(first["xyzmr"][:, 3].sum()) - float(last["xyzmr"][:, 3].sum())) <= 1e-3 * float(first["xyzmr"][:, 3].sum())
     if len(last) < len(first):
         assert last["xyzmr"][:, 4].max() > 2.0            # cbrt(2^3 + 2^3) > 2
+
+
+@pytest.mark.gpu
+def test_host_default_invocation(gpu, tmp_path):
+    """`nbody` with the reference's own defaults (main.go:17-24): 10 bodies + 2 cores, direct sum, collisions on,
+    frames rendered; a short run here (-y)."""
+    r = run(["-y", "0.002"], tmp_path)                      # frames = 17
+    assert r.returncode == 0, r.stdout.decode()
+    out = r.stdout.decode()
+    assert "collisions: true" in out and "tree: false" in out and "bodies: 12" in out
+    files = sorted(os.listdir(tmp_path / "frames"))
+    assert files == [f"{k:010d}.frame" for k in range(18)]
+    assert len(read_frame(tmp_path / "frames" / files[0])) == 12
