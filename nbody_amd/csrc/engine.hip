@@ -125,11 +125,29 @@ extern "C" int nbe_set_stream(nbe_engine* e, void* hip_stream)
     return NBE_OK;
 }
 
+static int upload_state(nbe_engine* e, size_t n, const double* pos, const double* vel, const double* mass, const uint64_t* id);
+
 extern "C" int nbe_upload(nbe_engine* e, size_t n, const double* pos, const double* vel, const double* mass, const uint64_t* id)
 {
     if (!e) { nbe_set_error("engine is NULL"); return NBE_E_INVALID; }
     if (n > 0 && (!pos || !vel || !mass)) { nbe_set_error("nbe_upload: NULL array"); return NBE_E_INVALID; }
     if (n > 0x7fffffffull) { nbe_set_error("at most 2^31-1 bodies"); return NBE_E_UNSUPPORTED; }
+    for (size_t i = 0; i < n; i++)
+        if (!(mass[i] >= 0.0)) { nbe_set_error("mass[%zu] is negative or NaN", i); return NBE_E_INVALID; }
+    const int rc = upload_state(e, n, pos, vel, mass, id);
+    if (rc != NBE_OK) {
+        // leave an empty engine behind rather than half of a state (the message of the failure is kept)
+        char msg[512];
+        snprintf(msg, sizeof(msg), "%s", g_err);
+        (void)free_state(e);
+        e->stats.n = 0; e->stats.n_alive = 0; e->host_nalive = 0; e->shard_count = 0;
+        nbe_set_error("%s", msg);
+    }
+    return rc;
+}
+
+static int upload_state(nbe_engine* e, size_t n, const double* pos, const double* vel, const double* mass, const uint64_t* id)
+{
     NBE_TRY(use_device(e));
     NBE_TRY(frame_stream_stop(e));
     NBE_HIP(hipStreamSynchronize(e->stream));

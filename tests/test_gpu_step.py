@@ -5,7 +5,7 @@ import sys
 import numpy as np
 import pytest
 
-from nbody_amd import Engine, physics
+from nbody_amd import Engine, EngineError, physics
 from oracle import oracle as O
 from tests.test_sharded_gloo import run_ranks
 
@@ -150,3 +150,20 @@ def test_tree_potential_at_scale_matches_pair_sum(gpu):
     assert abs(ke_t - ke_d) <= 1e-9 * ke_d
     assert abs(pe_t - pe_d) <= 2e-3 * abs(pe_d)
     assert abs(2 * ke_d / abs(pe_d) - 1.0) < 0.02
+
+
+def test_upload_rejects_bad_masses_and_leaves_an_empty_engine(gpu):
+    """A failed upload must not leave half a state behind: the engine is empty and usable afterwards."""
+    rng = np.random.default_rng(0)
+    pos = rng.uniform(-100, 100, (50, 3)); vel = np.zeros((50, 3)); mass = np.full(50, 10.0)
+    with Engine(mode="tree") as e:
+        e.upload(pos, vel, mass)
+        bad = mass.copy(); bad[7] = -1.0
+        with pytest.raises(EngineError, match=r"mass\[7\]"):
+            e.upload(pos, vel, bad)
+        bad[7] = np.nan
+        with pytest.raises(EngineError, match="negative or NaN"):
+            e.upload(pos, vel, bad)
+        e.upload(pos, vel, mass)                 # the previous state is untouched by a rejected upload
+        e.step(2)
+        assert len(e.download()[0]) == 50
