@@ -220,5 +220,21 @@ class Simulation:
         finally:
             self.engine.frame_stream_end()
 
+    def save(self, directory="."):
+        """exportFrameData (main.go:199-201, 210-224): the live bodies as a gob `frameJob` in `%010d.data`."""
+        from . import gobfile
+        f = self.frame()
+        return gobfile.export_frame_data(self.frame_index, f.ids, f.mass, f.radius, f.pos, f.vel, directory)
+
+    @classmethod
+    def resume(cls, filename, **kw):
+        """importFrameData + overwriteBodies (main.go:42-47, 226-248): a simulation that continues at the saved
+        frame number."""
+        from . import gobfile
+        frame, ids, mass, radius, pos, vel = gobfile.import_frame_data(filename)
+        sim = cls(Bodies(pos, vel, mass, ids, radius), **kw)
+        sim.frame_index = frame
+        return sim
+
     def close(self):
         self.engine.close()

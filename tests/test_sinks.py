@@ -1,4 +1,5 @@
 """The sqlite sink (database.go) above the frame stream."""
+import os
 import sqlite3
 
 import numpy as np
@@ -65,3 +66,51 @@ def test_simulation_streams_frames_into_sqlite(gpu, tmp_path, collide):
     final = sim.frame()
     sim.close()
     assert len(final) <= 302 and len(final.radius) == len(final)
+
+
+def test_chunk_store_files_and_round_trip(tmp_path):
+    """gob.go: frames collect per chunk, a full chunk becomes `%010d.chunk` named by its HIGH frame index, zlib
+    around a gob of map[frame]map[id]renderbody; the last chunk may hold fewer frames (gob.go:108-111)."""
+    from nbody_amd import sinks
+    rng = np.random.default_rng(0)
+    last_frame, per_chunk, n = 6, 3, 5
+    sink = sinks.ChunkSink(last_frame, per_chunk, compression_lvl=2, output_dir=str(tmp_path / "chunks"))
+    assert sink.expected == [3, 3, 1]
+    sent = {}
+    for frame in [1, 0, 2, 3, 6, 5, 4]:                       # workers deliver out of order
+        ids = np.arange(n, dtype=np.uint64) + 10
+        xyzm = rng.normal(0, 1e3, (n, 4)).astype(np.float32)
+        radius = np.full(n, 2.0, np.float32); radius[0] = 2.5198421
+        sent[frame] = (ids, xyzm, radius)
+        sink.write(frame, ids, xyzm, radius)
+    names = sorted(os.path.basename(f) for f in sink.files_written)
+    assert names == ["0000000002.chunk", "0000000005.chunk", "0000000008.chunk"]
+    assert sinks.determine_chunk_size_from_folder(str(tmp_path / "chunks")) == 3
+    chunk, low, high = sinks.read_chunk_from_frame(str(tmp_path / "chunks"), 4)
+    assert (low, high) == (3, 5) and sorted(chunk) == [3, 4, 5]
+    ids, xyzm, radius = sent[4]
+    for k, i in enumerate(ids):
+        b = chunk[4][int(i)]
+        assert (np.float32(b["X"]), np.float32(b["Y"]), np.float32(b["Z"]), np.float32(b["Mass"])) == tuple(xyzm[k])
+        assert np.float32(b["Radius"]) == radius[k]
+    assert sorted(sinks.read_chunk_from_filename(str(tmp_path / "chunks" / "0000000008.chunk"))) == [6]
+    assert sinks.ideal_chunk_size(50002) == 28 and sinks.frames_for_chunk(2, 3) == (6, 8)
+
+
+@pytest.mark.gpu
+def test_save_and_resume_through_gob(gpu, tmp_path):
+    """-save / -state (main.go:42-47, 199-201): a resumed run continues exactly where the saved one stood."""
+    b = physics.makebodies(200, seed=4)
+    sim = physics.Simulation(b, tree=True, precision="f64")
+    sim.step(5)
+    name = sim.save(str(tmp_path))
+    assert os.path.basename(name) == "0000000005.data"
+    sim.step(5)
+    want = sim.frame()
+    sim.close()
+    again = physics.Simulation.resume(name, tree=True, precision="f64")
+    assert again.frame_index == 5
+    again.step(5)
+    got = again.frame()
+    again.close()
+    assert np.array_equal(got.ids, want.ids) and np.array_equal(got.pos, want.pos) and np.array_equal(got.vel, want.vel)
