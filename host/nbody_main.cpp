@@ -6,7 +6,8 @@
 //   makebodies      physics.go:16-73 with the two cores of main.go:35-36
 //   frame loop      main.go:80-190  (frames+1 iterations; a frame copy goes to the workers BEFORE each step)
 //   output workers  main.go:50-61   4 consumers behind a queue of capacity 32 (here fed by nbe_frame_stream_begin)
-//   save / resume   main.go:199-248 (own little-endian binary format; the reference's gob files need Go)
+//   save / resume   main.go:199-248 (the reference's gob stream of a frameJob, host/gob.hpp; -recode FILE reads a
+//                   state file and writes it back as %010d.data, without touching the GPU)
 // The step itself (main.go:104-178) is one nbe_step call, collisions included: in tree mode the search, queue and
 // merge of tree.go:245-281 / main.go:151-167, in the direct sum the merge inside the pair sweep (main.go:122-126).
 // The reference's sinks are a PNG renderer, a gob chunk store and sqlite; the sink here writes the record the
@@ -26,6 +27,7 @@
 #include <thread>
 #include <vector>
 
+#include "gob.hpp"
 #include "nbody_engine.h"
 
 // physics.go:91-98
@@ -99,43 +101,49 @@ static std::vector<body> makebodies(int n, std::vector<body> cores, uint64_t see
     return bodies;
 }
 
-// ---- save / resume (main.go:210-248) ----
+// ---- save / resume (main.go:210-248): the reference's own file, a gob stream of the frameJob ----
 static void exportFrameData(const frameJob& frame)
 {
     char fname[64];
     std::snprintf(fname, sizeof(fname), "%010d.data", frame.Frame);      // main.go:211
+    gob::FrameJob job;
+    job.Frame = frame.Frame;
+    job.Bodies.reserve(frame.Bodies.size());
+    for (const body& b : frame.Bodies) {   // exported fields only (physics.go:92-96); the force accumulators do not travel
+        gob::Body g;
+        g.ID = b.ID; g.Mass = b.Mass; g.Radius = b.Radius; g.X = b.X; g.Y = b.Y; g.Z = b.Z; g.Vx = b.Vx; g.Vy = b.Vy; g.Vz = b.Vz;
+        job.Bodies.push_back(g);
+    }
+    const std::string bytes = gob::encode(job);
     FILE* f = std::fopen(fname, "wb");
     if (!f) panic(std::string("cannot create ") + fname);
-    const uint64_t magic = 0x3179646f626e424eull, n = frame.Bodies.size();
-    const int64_t fr = frame.Frame;
-    bool ok = std::fwrite(&magic, 8, 1, f) == 1 && std::fwrite(&fr, 8, 1, f) == 1 && std::fwrite(&n, 8, 1, f) == 1;
-    for (const body& b : frame.Bodies) {   // exported fields only, like gob (physics.go:92-96); forces do not travel
-        const double rec[9] = {(double)b.ID, b.Mass, b.Radius, b.X, b.Y, b.Z, b.Vx, b.Vy, b.Vz};
-        ok = ok && std::fwrite(rec, sizeof(rec), 1, f) == 1;
-    }
+    const bool ok = std::fwrite(bytes.data(), 1, bytes.size(), f) == bytes.size();
     std::fclose(f);
-    if (!ok) { std::remove(fname); panic(std::string("write failed: ") + fname); }
+    if (!ok) { std::remove(fname); panic(std::string("write failed: ") + fname); }   // main.go:220-223
 }
 
 static frameJob importFrameData(const std::string& filename)
 {
     FILE* f = std::fopen(filename.c_str(), "rb");
     if (!f) panic("cannot open " + filename);
-    uint64_t magic = 0, n = 0;
-    int64_t fr = 0;
-    if (std::fread(&magic, 8, 1, f) != 1 || magic != 0x3179646f626e424eull || std::fread(&fr, 8, 1, f) != 1 ||
-        std::fread(&n, 8, 1, f) != 1)
-        panic("not a state file: " + filename);
-    frameJob job;
-    job.Frame = (int)fr;
-    job.Bodies.resize((size_t)n);
-    for (body& b : job.Bodies) {
-        double rec[9];
-        if (std::fread(rec, sizeof(rec), 1, f) != 1) panic("truncated state file: " + filename);
-        b.ID = (uint64_t)rec[0]; b.Mass = rec[1]; b.Radius = rec[2];
-        b.X = rec[3]; b.Y = rec[4]; b.Z = rec[5]; b.Vx = rec[6]; b.Vy = rec[7]; b.Vz = rec[8];
-    }
+    std::string bytes;
+    char buf[1 << 16];
+    for (size_t k; (k = std::fread(buf, 1, sizeof(buf), f)) > 0;) bytes.append(buf, k);
     std::fclose(f);
+    gob::FrameJob g;
+    try {
+        g = gob::decode(bytes.data(), bytes.size());
+    } catch (const std::exception& ex) {
+        panic(filename + ": " + ex.what());                                // main.go:236-238
+    }
+    frameJob job;
+    job.Frame = (int)g.Frame;
+    job.Bodies.resize(g.Bodies.size());
+    for (size_t k = 0; k < g.Bodies.size(); k++) {
+        body& b = job.Bodies[k];
+        const gob::Body& s = g.Bodies[k];
+        b.ID = s.ID; b.Mass = s.Mass; b.Radius = s.Radius; b.X = s.X; b.Y = s.Y; b.Z = s.Z; b.Vx = s.Vx; b.Vy = s.Vy; b.Vz = s.Vz;
+    }
     return job;
 }
 
@@ -247,6 +255,7 @@ int main(int argc, char** argv)
         else if (const char* v = val("-theta")) theta = std::atof(v);
         else if (const char* v = val("-frames-dir")) framesDir = v;
         else if (const char* v = val("-precision")) precision = !std::strcmp(v, "f64") ? NBE_PREC_F64 : !std::strcmp(v, "mixed") ? NBE_PREC_MIXED : NBE_PREC_F32;
+        else if (const char* v = val("-recode")) { exportFrameData(importFrameData(v)); return 0; }
         else if (a == "-save") stateSave = true;
         else if (a == "-tree") tree = true;
         else if (a == "-norender") norender = true;

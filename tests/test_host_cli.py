@@ -94,3 +94,26 @@ def test_host_default_invocation(gpu, tmp_path):
     files = sorted(os.listdir(tmp_path / "frames"))
     assert files == [f"{k:010d}.frame" for k in range(18)]
     assert len(read_frame(tmp_path / "frames" / files[0])) == 12
+
+
+def test_state_files_are_the_same_gob_stream_in_both_hosts(tmp_path):
+    """-save / -state (main.go:199-248): the C++ host (host/gob.hpp) and the Python host (nbody_amd/gobfile.py) write
+    the same bytes for the same frameJob and read each other's files; -recode needs no GPU."""
+    from nbody_amd import gobfile as G
+    rng = np.random.default_rng(5)
+    n = 40
+    ids = np.arange(n, dtype=np.uint64); ids[3] = 2 ** 40 + 1
+    mass = np.abs(rng.normal(1e3, 500, n)); radius = np.full(n, 2.0); radius[0] = 1.0
+    pos = rng.normal(0, 1e3, (n, 3)); vel = rng.normal(0, 1e-2, (n, 3))
+    vel[5] = 0.0; pos[6, 1] = 0.0; mass[7] = 0.0                      # zero fields are left out of the stream
+    src = tmp_path / "in"; src.mkdir()
+    name = G.export_frame_data(36, ids, mass, radius, pos, vel, directory=str(src))
+    r = run(["-recode", name], tmp_path)
+    assert r.returncode == 0, r.stdout.decode()
+    out = tmp_path / "0000000036.data"
+    assert out.read_bytes() == open(name, "rb").read()
+    f, i2, m2, r2, p2, v2 = G.import_frame_data(str(out))
+    assert f == 36 and np.array_equal(i2, ids) and np.array_equal(m2, mass) and np.array_equal(p2, pos) and np.array_equal(v2, vel)
+    bad = tmp_path / "bad.data"; bad.write_bytes(open(name, "rb").read()[:-5])
+    r = run(["-recode", str(bad)], tmp_path)
+    assert r.returncode == 2 and b"gob" in r.stdout
