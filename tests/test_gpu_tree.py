@@ -286,3 +286,25 @@ def test_single_workgroup_sort_equals_tiled_sort(gpu, monkeypatch, n, precision)
         out.append((acc, alive, nodes, p, v, ids))
     for a, b in zip(out[0], out[1]):
         assert np.array_equal(a, b, equal_nan=True)
+
+
+def test_16m_plummer_on_one_gpu(gpu):
+    """Benchmark configuration 4's body count (16,777,216) on a single GPU: nothing is lost in the sort, the node
+    bookkeeping holds, and a sample of bodies agrees with the fp64 direct sum over all 16M sources to the accuracy
+    theta = 0.5 gives at 1M bodies."""
+    n = 1 << 24
+    b = physics.plummer(n, seed=2)
+    pos, mass = f32(b.pos), f32(b.mass)
+    with Engine(mode="tree", precision="f32", theta=0.5) as e:
+        e.upload(pos, b.vel, mass)
+        acc, alive = e.accel()
+        st = e.stats()
+        e.step(1)
+        st2 = e.stats()
+    assert alive.all() and st.n_alive == n and st2.n_alive == n
+    assert st.tree_nodes == n + st.tree_cells and 0 < st.tree_cells < n
+    assert 1500 * n < st.interactions < 3000 * n
+    sample = np.arange(12345, n, n // 48)[:48]
+    ref = np.concatenate([O.direct_rows(mass, pos, t0=int(t), t1=int(t) + 1) for t in sample]) / mass[sample][:, None]
+    er = relerr(acc[sample], ref)
+    assert np.median(er) <= 1e-2 and er.max() <= 8e-2
