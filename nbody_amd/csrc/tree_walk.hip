@@ -84,7 +84,9 @@ __device__ __forceinline__ bool node_opens(const RawD& nd, double r2, double the
 // Tried: handing subtrees that at most 16 lanes open to those lanes for private walks with vector loads after
 // the shared walk.  It removes 31 % of the shared visits, but a private step (two vector loads with up to 64
 // different addresses) costs three shared visits and the remaining shared visits are the cache-unfriendly ones:
-// 2.04 ms against 2.07 ms, not worth its complexity.
+// 2.04 ms against 2.07 ms, not worth its complexity.  A scalar branch that spares leaves (which cannot open) the
+// test, the vote and the sit-out update saves six vector instructions on paper; the compiler pays them back in
+// register copies and mask bookkeeping at the join (2.21 ms with both arms written out, 2.49 ms with a shared tail).
 template <typename R, typename A, typename NodeT, int OUT, bool COUNT, bool SOFT, int NS>
 __global__ __launch_bounds__(WALK_BLOCK) void walk_kernel(
     const NodeT* __restrict__ nodes, const int* __restrict__ counters, const typename V4<R>::type* __restrict__ posm,
