@@ -74,7 +74,8 @@ def test_negative_zero_is_treated_like_zero(gpu):
         acc, alive = e.accel()
     assert alive.all()
     ref = O.direct_rows(mass, np.abs(pos) * np.sign(pos + 1e-300)) / mass[:, None]
-    assert relerr(acc, ref).max() <= 1e-12
+    # the middle body feels two equal and opposite pulls: compare with the size of one of them, not with their sum
+    assert np.abs(acc - ref).max() <= 1e-12 * np.abs(ref).max()
 
 
 @pytest.mark.parametrize("theta", [0.0, 0.3, 0.5, 1.0, 2.0, 1e9])
