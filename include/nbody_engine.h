@@ -135,12 +135,15 @@ int nbe_energy(nbe_engine *e, double *kinetic, double *potential, double momentu
  * The reference's only data-parallel strategy is to give each of 4 goroutines a contiguous quarter of the
  * bodies against a shared read-only tree (main.go:134-149); a shard is that quarter.
  *   nbe_set_shard(first, count)   targets [first, first+count) in device order belong to this engine
+ *   nbe_shard_sort                optional, tree mode: the part of the sort that reads positions only (keys, radix
+ *                                 passes), so that it can run while the velocities of the other engines still arrive
  *   nbe_shard_prepare             tree mode: sort by Morton key, reorder state, build the tree (replicated)
  *   nbe_shard_advance             forces on the shard + fused update, written into *_next at the same indices
  *   (caller all-gathers pos_mass_next and vel_next across engines)
  *   nbe_shard_commit              *_next become current
  * nbe_step is prepare + advance over all bodies + commit. */
 int nbe_set_shard(nbe_engine *e, uint64_t first, uint64_t count);
+int nbe_shard_sort(nbe_engine *e);
 int nbe_shard_prepare(nbe_engine *e);
 int nbe_shard_advance(nbe_engine *e);
 int nbe_shard_commit(nbe_engine *e);

@@ -154,7 +154,7 @@ static int upload_state(nbe_engine* e, size_t n, const double* pos, const double
     NBE_TRY(free_state(e));
     e->n = n;
     e->cur = 0; e->orig_cur = 0;
-    e->prepared = false; e->advance_pending = false; e->have_counts = false;
+    e->prepared = false; e->advance_pending = false; e->have_counts = false; e->keys_sorted = false;
     e->shard_set = false; e->shard_first = 0; e->shard_count = n;
     memset(&e->stats, 0, sizeof(e->stats));
     e->stats.n = n; e->stats.n_alive = n;
@@ -376,6 +376,16 @@ extern "C" int nbe_shard_prepare(nbe_engine* e)
     if (e->cfg.mode == NBE_MODE_TREE && !e->prepared) NBE_TRY(tree_sort_and_build(e));
     e->prepared = true;
     return NBE_OK;
+}
+
+extern "C" int nbe_shard_sort(nbe_engine* e)
+{
+    if (!e) { nbe_set_error("engine is NULL"); return NBE_E_INVALID; }
+    if (e->cfg.collisions) { nbe_set_error("sharded stepping does not support collisions; use nbe_step"); return NBE_E_UNSUPPORTED; }
+    NBE_TRY(use_device(e));
+    if (e->advance_pending) { nbe_set_error("nbe_shard_sort before nbe_shard_commit"); return NBE_E_INVALID; }
+    if (e->cfg.mode != NBE_MODE_TREE || e->prepared) return NBE_OK;
+    return tree_sort_keys(e);
 }
 
 extern "C" int nbe_shard_advance(nbe_engine* e)

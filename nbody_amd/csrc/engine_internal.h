@@ -168,6 +168,7 @@ struct nbe_engine {
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     uint64_t shard_first = 0, shard_count = 0;
     bool shard_set = false;
+    bool keys_sorted = false;       // tree mode: keys of the current state are sorted already (nbe_shard_sort ran)
     bool prepared = false;          // tree of the current state is valid
     bool advance_pending = false;   // *_next hold an advanced shard waiting for nbe_shard_commit
     TreeWork tw;
@@ -183,6 +184,7 @@ int direct_forces(nbe_engine* e, int src_buf, uint64_t t0, uint64_t t1, bool fus
 // tree_build.hip
 int tree_workspace_reserve(nbe_engine* e);
 int tree_small_limit(void);
+int tree_sort_keys(nbe_engine* e);              // optional first half of tree_sort_and_build (reads positions only)
 int tree_sort_and_build(nbe_engine* e);         // sorts cur -> cur^1, flips e->cur, builds the tree
 // tree_walk.hip
 int tree_forces(nbe_engine* e, int src_buf, uint64_t t0, uint64_t t1, bool fused, bool count, int dst_buf);

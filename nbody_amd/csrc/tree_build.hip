@@ -769,30 +769,30 @@ int tree_workspace_reserve(nbe_engine* e)
     return NBE_OK;
 }
 
-template <typename R4, typename S4, typename NodeT>
-static int sort_and_build_t(nbe_engine* e)
+// Keys of the current state and their sorted order (w.keys[0], w.sidx[0], live count): everything of the sort that
+// reads positions only.  The state itself is reordered afterwards, by sort_and_build_t.
+template <typename R4>
+static int sort_keys_t(nbe_engine* e)
 {
     TreeWork& w = e->tw;
     const int n = (int)e->n;
-    const int cur = e->cur, nxt = cur ^ 1;
+    const int cur = e->cur;
     const unsigned nb = cdiv(n, 256);
     const bool mixed = e->cfg.precision == NBE_PREC_MIXED;
     const R4* force_pos = mixed ? (const R4*)e->mirror[cur] : (const R4*)e->posm[cur];
     const double W = e->cfg.bound_width;
     const double lox = e->cfg.bound_center[0] - 0.5 * W, loy = e->cfg.bound_center[1] - 0.5 * W,
                  loz = e->cfg.bound_center[2] - 0.5 * W;
-
-    if (e->timing) NBE_HIP(hipEventRecord(e->ev[0], e->stream));
     NBE_HIP(hipMemsetAsync(w.counters, 0, 4 * sizeof(int), e->stream));
     if (n <= e->small_max) {
         hipLaunchKernelGGL((small_sort_kernel<R4>), dim3(1), dim3(1024), 0, e->stream, force_pos, n, lox, loy, loz, W, w.keys[0],
                            w.sidx[0], w.counters);
         NBE_HIP(hipGetLastError());
-    } else {
+        return NBE_OK;
+    }
     hipLaunchKernelGGL((keys_kernel<R4>), dim3(nb), dim3(256), 0, e->stream, force_pos, n, lox, loy, loz, W, w.keys[0],
                        w.sidx[0], w.counters);
     NBE_HIP(hipGetLastError());
-
     // 63-bit keys plus the all-ones dead key: 8 passes of 8 bits, ending back in buffer 0.
     const int nblocks = (int)cdiv(n, SORT_TILE);
     int in = 0;
@@ -807,7 +807,22 @@ static int sort_and_build_t(nbe_engine* e)
         NBE_HIP(hipGetLastError());
         in ^= 1;
     }
-    }
+    return NBE_OK;
+}
+
+template <typename R4, typename S4, typename NodeT>
+static int sort_and_build_t(nbe_engine* e)
+{
+    TreeWork& w = e->tw;
+    const int n = (int)e->n;
+    const int cur = e->cur, nxt = cur ^ 1;
+    const unsigned nb = cdiv(n, 256);
+    const bool mixed = e->cfg.precision == NBE_PREC_MIXED;
+    const double W = e->cfg.bound_width;
+
+    if (e->timing) NBE_HIP(hipEventRecord(e->ev[0], e->stream));
+    if (!e->keys_sorted) NBE_TRY(sort_keys_t<R4>(e));        // unless tree_sort_keys ran ahead of this call
+    e->keys_sorted = false;
     NBE_TRY(frame_stream_guard_write(e, nxt));
     hipLaunchKernelGGL((permute_kernel<S4>), dim3(nb), dim3(256), 0, e->stream, w.sidx[0], n, (const S4*)e->posm[cur],
                        (const S4*)e->vel[cur], e->orig[e->orig_cur], mixed ? e->mirror[cur] : (const float4*)nullptr,
@@ -859,6 +874,18 @@ static int sort_and_build_t(nbe_engine* e)
 int device_scan_u32(nbe_engine* e, const uint32_t* in, uint32_t* out, size_t len)
 {
     return device_exclusive_scan<false>(e, in, out, len);
+}
+
+// The part of the sort that needs positions only, ahead of tree_sort_and_build: a host that still waits for other
+// state arrays to arrive (velocities from other GPUs) can let this run meanwhile.
+int tree_sort_keys(nbe_engine* e)
+{
+    NBE_TRY(tree_workspace_reserve(e));
+    if (e->n == 0 || e->keys_sorted) return NBE_OK;
+    if (e->n > 0x3fffffffull) { nbe_set_error("tree mode supports at most 2^30-1 bodies"); return NBE_E_UNSUPPORTED; }
+    int rc = e->cfg.precision == NBE_PREC_F64 ? sort_keys_t<double4>(e) : sort_keys_t<float4>(e);
+    if (rc == NBE_OK) e->keys_sorted = true;
+    return rc;
 }
 
 // Sorts the current state by Morton key into the other buffer (which becomes current) and builds the tree

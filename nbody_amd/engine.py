@@ -20,7 +20,7 @@ EXPORTS = ("nbe_default_config", "nbe_create", "nbe_destroy", "nbe_last_error", 
            "nbe_accel", "nbe_step", "nbe_step_timed", "nbe_sync", "nbe_stats", "nbe_energy", "nbe_set_shard",
            "nbe_shard_prepare", "nbe_shard_advance", "nbe_shard_commit", "nbe_device_state", "nbe_set_stream",
            "nbe_time_force_kernel", "nbe_tree_nodes", "nbe_frame_stream_begin", "nbe_frame_stream_end",
-           "nbe_set_radius", "nbe_get_radius")
+           "nbe_set_radius", "nbe_get_radius", "nbe_shard_sort")
 
 FRAME_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_size_t, C.POINTER(C.c_float), C.POINTER(C.c_float),
                        C.POINTER(C.c_uint64))
@@ -83,6 +83,7 @@ def load_library():
     lib.nbe_stats.argtypes = [vp, C.POINTER(Stats)]
     lib.nbe_energy.argtypes = [vp, dp, dp, dp]
     lib.nbe_set_shard.argtypes = [vp, C.c_uint64, C.c_uint64]
+    lib.nbe_shard_sort.argtypes = [vp]
     lib.nbe_shard_prepare.argtypes = [vp]
     lib.nbe_shard_advance.argtypes = [vp]
     lib.nbe_shard_commit.argtypes = [vp]
@@ -263,6 +264,9 @@ class Engine:
     # ---- sharded stepping ----
     def set_shard(self, first, count):
         self._check(self._lib.nbe_set_shard(self._h, int(first), int(count)))
+
+    def shard_sort(self):
+        self._check(self._lib.nbe_shard_sort(self._h))
 
     def shard_prepare(self):
         self._check(self._lib.nbe_shard_prepare(self._h))

@@ -56,6 +56,10 @@ class EngineShard:
     def prepare(self):
         self.engine.shard_prepare()
 
+    def sort_ahead(self):
+        """The part of the next step's sort that needs positions only (nbe_shard_sort)."""
+        self.engine.shard_sort()
+
     def advance(self):
         self.engine.shard_advance()
 
@@ -113,10 +117,27 @@ class ShardedStepper:
         if host_stage:
             full.copy_(work)
 
+    def _gather_async(self, full):
+        """The same exchange as a non-blocking collective, where the backend runs it beside the compute stream
+        (RCCL, device buffers, equal ranges); returns the work handle, or None after a blocking exchange."""
+        if self.world == 1 and not self.always_gather:
+            return None
+        if self.backend != "nccl" or not self.even or not full.is_cuda:
+            self._gather(full)
+            return None
+        return dist.all_gather_into_tensor(full, full[self.first:self.first + self.count], group=self.group, async_op=True)
+
     def step(self, nsteps=1):
+        """Per step: build (replicated), advance the own range, exchange positions, then velocities.  Only the
+        positions are needed to start the next step (keys and radix passes), so the velocity exchange runs beside
+        that sort when the shard offers `sort_ahead`; the stream waits for it before the state is reordered."""
         for _ in range(nsteps):
             self.shard.prepare()
             self.shard.advance()
-            for t in self.shard.next_state():
-                self._gather(t)
+            pos, vel = self.shard.next_state()
+            self._gather(pos)
+            pending = self._gather_async(vel) if hasattr(self.shard, "sort_ahead") else (self._gather(vel), None)[1]
             self.shard.commit()
+            if pending is not None:
+                self.shard.sort_ahead()
+                pending.wait()          # a stream dependency, not a host wait

@@ -196,3 +196,37 @@ def test_steps_can_be_captured_in_a_hip_graph(gpu, mode):
         e.set_stream(None)
     for a, w in zip(got, want):
         assert np.array_equal(a, w)
+
+
+@pytest.mark.parametrize("mode,precision", [("tree", "f32"), ("tree", "mixed"), ("direct", "f32")])
+def test_single_rank_rccl_stepper_with_overlapped_velocity_exchange(gpu, mode, precision):
+    """The RCCL path of ShardedStepper on one GPU (one-rank "nccl" group, collectives forced): positions are
+    exchanged first, the velocity exchange runs beside the next step's key sort (nbe_shard_sort), and the result
+    equals plain nbe_step bit for bit."""
+    import torch
+    import torch.distributed as dist
+    from nbody_amd.sharded import EngineShard, ShardedStepper
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29577")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        b = physics.plummer(20000, seed=8, a=3e3)
+        with Engine(mode=mode, precision=precision, theta=0.6) as plain:
+            plain.upload(b.pos, b.vel, b.mass)
+            plain.step(6)
+            want = plain.download()
+        with Engine(mode=mode, precision=precision, theta=0.6) as e:
+            e.upload(b.pos, b.vel, b.mass)
+            st = ShardedStepper(EngineShard(e, device_index=0), rank=0, world=1, always_gather=True)
+            assert st.backend == "nccl"
+            st.step(6)
+            torch.cuda.synchronize()
+            got = e.download()
+            e.set_stream(None)
+        for a, w in zip(got, want):
+            assert np.array_equal(a, w)
+    finally:
+        if created:
+            dist.destroy_process_group()
