@@ -94,5 +94,44 @@ def main():
     print("wrote", OUT, os.path.getsize(OUT), "bytes")
 
 
+OUT_COLLIDE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden_collide.npz")
+
+
+def main_collide():
+    """golden_collide.npz: crowded scenes stepped with collisions on (tree: tree.go:245-281 + main.go:151-167;
+    direct: main.go:107-128), outputs of the C restatement, checked against the Python one before writing
+    (radii to a few ulp: the two use different cube roots)."""
+    out = {}
+    for name, n, half, seed in (("crowd120", 120, 14.0, 31), ("crowd400", 400, 24.0, 32)):
+        rng = np.random.default_rng(seed)
+        pos = rng.uniform(-half, half, (n, 3)); vel = rng.normal(0, 1e-3, (n, 3))
+        mass = np.abs(rng.normal(1e3, 500, n)) + 1; rad = rng.uniform(0.5, 3.0, n)
+        out[f"{name}/mass"], out[f"{name}/pos"], out[f"{name}/vel"], out[f"{name}/radius"] = mass, pos, vel, rad
+        for tag, kw, pykw in (("direct", dict(mode="direct"), dict(tree=False)),
+                              ("tree_ref", dict(mode="tree", com_mode="ref", theta=1.0, drop_tail=True),
+                               dict(tree=True, theta=1.0, true_com=False, drop_tail=True)),
+                              ("tree_true", dict(mode="tree", com_mode="true", theta=0.7, drop_tail=False, max_depth=21),
+                               dict(tree=True, theta=0.7, true_com=True, drop_tail=False))):
+            m, r, p, v, alive, st = O.step_collide(mass, rad, pos, vel, nsteps=4, dt=100.0, **kw)
+            assert st.merges > 0, (name, tag)
+            bodies = [P.Body(i, float(mass[i]), float(rad[i]), *map(float, pos[i]), *map(float, vel[i])) for i in range(n)]
+            P.simulate(bodies, 4, dt=100.0, collide=True, **pykw)
+            assert [bb is not None for bb in bodies] == [bool(a) for a in alive], (name, tag)
+            for i, bb in enumerate(bodies):
+                if bb is not None:
+                    assert bb.Mass == m[i] and abs(bb.Radius - r[i]) <= 1e-15 * r[i], (name, tag, i)
+                    assert max(abs(bb.X - p[i, 0]), abs(bb.Y - p[i, 1]), abs(bb.Z - p[i, 2])) <= 1e-13 * half, (name, tag, i)
+            key = f"{name}/step4_{tag}"
+            out[key + "_mass"], out[key + "_radius"], out[key + "_pos"], out[key + "_vel"] = m, r, p, v
+            out[key + "_alive"] = alive
+            out[key + "_meta"] = np.array([st.merges, st.queued])
+        print(f"{name}: ok")
+    np.savez_compressed(OUT_COLLIDE, **out)
+    print("wrote", OUT_COLLIDE, os.path.getsize(OUT_COLLIDE), "bytes")
+
+
 if __name__ == "__main__":
-    main()
+    if "collide" in sys.argv[1:]:
+        main_collide()
+    else:
+        main()

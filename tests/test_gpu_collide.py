@@ -322,3 +322,26 @@ def test_direct_frames_and_energy_leave_out_absorbed_bodies(gpu):
     assert int(st.n_alive) == int(oalive.sum()) < 500
     oke, ope, omom = O.energy(om, op, ov, alive=oalive)
     assert abs(ke - oke) <= 1e-9 * abs(oke) and abs(pe - ope) <= 1e-9 * abs(ope)
+
+
+@pytest.mark.parametrize("name", ["crowd120", "crowd400"])
+@pytest.mark.parametrize("mode", ["direct", "tree"])
+def test_engine_against_the_collision_golden_vectors(gpu, name, mode):
+    """The committed fixtures (tests/golden/golden_collide.npz): four steps with merges, fp64 engine."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_collide.npz"), allow_pickle=False)
+    mass, pos, vel, rad = (g[f"{name}/{k}"] for k in ("mass", "pos", "vel", "radius"))
+    key = f"{name}/step4_" + ("direct" if mode == "direct" else "tree_true")
+    with Engine(mode=mode, precision="f64", collisions=True, theta=0.7, dt=100.0) as e:
+        e.upload(pos, vel, mass)
+        e.set_radius(rad)
+        e.step(4)
+        p, v, m, ids = e.download()
+        r = e.get_radius()
+        st = e.stats()
+    live = g[key + "_alive"] == 1
+    assert np.array_equal(ids, np.nonzero(live)[0].astype(np.uint64)) and int(st.merges) == int(g[key + "_meta"][0])
+    assert np.abs(m - g[key + "_mass"][live]).max() <= 1e-12 * m.max()
+    assert np.abs(r - g[key + "_radius"][live]).max() <= 1e-13 * r.max()
+    assert np.abs(p - g[key + "_pos"][live]).max() <= 1e-11 * np.abs(p).max()
+    assert np.abs(v - g[key + "_vel"][live]).max() <= 1e-9 * np.abs(v).max()

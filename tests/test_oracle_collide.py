@@ -102,3 +102,23 @@ def test_collisions_off_is_the_old_step():
     far = np.full(len(mass), 1e-9)                              # radii too small to touch anything
     m2, r2, p2, v2, a2, st = O.step_collide(mass, far, pos, vel, nsteps=2, mode="tree", dt=50.0)
     assert st.merges == 0 and np.array_equal(p1, p2) and np.array_equal(v1, v2) and np.array_equal(a1, a2)
+
+
+GOLDEN_COLLIDE = __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.abspath(__file__)), "golden", "golden_collide.npz")
+STEP_KW = {"direct": dict(mode="direct"),
+           "tree_ref": dict(mode="tree", com_mode="ref", theta=1.0, drop_tail=True),
+           "tree_true": dict(mode="tree", com_mode="true", theta=0.7, drop_tail=False, max_depth=21)}
+
+
+@pytest.mark.parametrize("name", ["crowd120", "crowd400"])
+@pytest.mark.parametrize("tag", ["direct", "tree_ref", "tree_true"])
+def test_collision_golden_vectors(name, tag):
+    """tests/golden/golden_collide.npz (made by tests/golden/make_golden.py collide): four steps with merges."""
+    g = np.load(GOLDEN_COLLIDE, allow_pickle=False)
+    mass, pos, vel, rad = (g[f"{name}/{k}"] for k in ("mass", "pos", "vel", "radius"))
+    m, r, p, v, alive, st = O.step_collide(mass, rad, pos, vel, nsteps=4, dt=100.0, **STEP_KW[tag])
+    key = f"{name}/step4_{tag}"
+    assert np.array_equal(alive, g[key + "_alive"]) and [st.merges, st.queued] == list(g[key + "_meta"])
+    live = alive == 1
+    assert np.array_equal(m[live], g[key + "_mass"][live]) and np.array_equal(p[live], g[key + "_pos"][live])
+    assert np.array_equal(v[live], g[key + "_vel"][live]) and np.array_equal(r[live], g[key + "_radius"][live])
