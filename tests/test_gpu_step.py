@@ -233,3 +233,22 @@ def test_single_rank_rccl_stepper_with_overlapped_velocity_exchange(gpu, mode, p
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_two_engines_in_one_process_do_not_share_state(gpu):
+    """Engines own their streams and workspaces: two of them stepped in turn give what each gives alone."""
+    b1 = physics.makebodies(1500, seed=1); b2 = physics.plummer(2500, seed=2)
+    alone = []
+    for b, mode in ((b1, "tree"), (b2, "direct")):
+        with Engine(mode=mode, precision="f32") as e:
+            e.upload(b.pos, b.vel, b.mass)
+            e.step(6)
+            alone.append(e.download())
+    with Engine(mode="tree", precision="f32") as e1, Engine(mode="direct", precision="f32") as e2:
+        e1.upload(b1.pos, b1.vel, b1.mass); e2.upload(b2.pos, b2.vel, b2.mass)
+        for _ in range(3):
+            e1.step(2); e2.step(2)
+        got = [e1.download(), e2.download()]
+    for g, a in zip(got, alone):
+        for x, y in zip(g, a):
+            assert np.array_equal(x, y)
