@@ -722,6 +722,9 @@ static int free_ptr(void** p)
     return NBE_OK;
 }
 
+// Up to 2n - 1 nodes plus the sentinel; the walk addresses fp32 node records with a 32-bit byte offset (32 B each).
+#define TREE_MAX_BODIES (1ull << 26)
+
 int tree_small_limit(void) { return SMALL_SORT_MAX; }
 
 int tree_workspace_reserve(nbe_engine* e)
@@ -882,7 +885,7 @@ int tree_sort_keys(nbe_engine* e)
 {
     NBE_TRY(tree_workspace_reserve(e));
     if (e->n == 0 || e->keys_sorted) return NBE_OK;
-    if (e->n > 0x3fffffffull) { nbe_set_error("tree mode supports at most 2^30-1 bodies"); return NBE_E_UNSUPPORTED; }
+    if (e->n > TREE_MAX_BODIES) { nbe_set_error("tree mode supports at most 2^26 bodies"); return NBE_E_UNSUPPORTED; }
     int rc = e->cfg.precision == NBE_PREC_F64 ? sort_keys_t<double4>(e) : sort_keys_t<float4>(e);
     if (rc == NBE_OK) e->keys_sorted = true;
     return rc;
@@ -894,7 +897,7 @@ int tree_sort_and_build(nbe_engine* e)
 {
     NBE_TRY(tree_workspace_reserve(e));
     if (e->n == 0) return NBE_OK;
-    if (e->n > 0x3fffffffull) { nbe_set_error("tree mode supports at most 2^30-1 bodies"); return NBE_E_UNSUPPORTED; }
+    if (e->n > TREE_MAX_BODIES) { nbe_set_error("tree mode supports at most 2^26 bodies"); return NBE_E_UNSUPPORTED; }
     switch (e->cfg.precision) {
     case NBE_PREC_F32: return sort_and_build_t<float4, float4, NodeF>(e);
     case NBE_PREC_MIXED: return sort_and_build_t<float4, double4, NodeF>(e);

@@ -252,3 +252,14 @@ def test_two_engines_in_one_process_do_not_share_state(gpu):
     for g, a in zip(got, alone):
         for x, y in zip(g, a):
             assert np.array_equal(x, y)
+
+
+def test_tree_body_limit():
+    """Tree mode addresses node records with 32-bit byte offsets: more than 2^26 bodies are refused at upload,
+    before any array is read (the zero pages below are never touched)."""
+    n = (1 << 26) + 1
+    z3 = np.zeros((n, 3)); z1 = np.zeros(n)
+    with Engine(mode="tree", precision="f32") as e:
+        with pytest.raises(EngineError, match="2\\^26"):
+            e.upload(z3, z3, z1)
+        assert e.stats().n == 0
