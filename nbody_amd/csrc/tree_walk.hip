@@ -40,6 +40,27 @@ __device__ __forceinline__ RawD load_raw(const NodeD* __restrict__ nodes, int i)
     const int sk = *reinterpret_cast<const int*>(reinterpret_cast<const char*>(nodes + i) + 40);
     return RawD{a.x, a.y, a.z, a.w, w.x, sk};
 }
+// The same request split in two: `request_raw` issues the load and returns at once, `arrived` waits for it.  The
+// compiler schedules a plain load next to its first use, which in the walk is one whole visit too late.
+struct PendingF { unsigned v __attribute__((ext_vector_type(8))); };
+struct PendingD { RawD r; };
+// `after` is passed through a second statement that the compiler may not move ahead of the request: whatever is
+// computed from it stays behind the request in program order.
+__device__ __forceinline__ PendingF request_raw(const NodeF* __restrict__ nodes, int i, float& after)
+{
+    PendingF p;
+    asm volatile("s_load_dwordx8 %0, %1, %2" : "=s"(p.v) : "s"(nodes), "s"((unsigned)i * 32u));
+    asm volatile("" : "+v"(after));
+    return p;
+}
+__device__ __forceinline__ RawF arrived(PendingF& p)
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(p.v));
+    return RawF{p.v[0], p.v[1], p.v[2], p.v[3], p.v[4], (int)p.v[5]};
+}
+__device__ __forceinline__ PendingD request_raw(const NodeD* __restrict__ nodes, int i, double&) { return PendingD{load_raw(nodes, i)}; }
+__device__ __forceinline__ RawD arrived(PendingD& p) { return p.r; }
+
 __device__ __forceinline__ RawF pick(bool c, const RawF& a, const RawF& b)
 {
     return RawF{c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z, c ? a.m : b.m, c ? a.w2 : b.w2, c ? a.skip : b.skip};
@@ -87,7 +108,14 @@ __device__ __forceinline__ bool node_opens(const RawD& nd, double r2, double the
 // 2.04 ms against 2.07 ms, not worth its complexity.  A scalar branch that spares leaves (which cannot open) the
 // test, the vote and the sit-out update saves six vector instructions on paper; the compiler pays them back in
 // register copies and mask bookkeeping at the join (2.21 ms with both arms written out, 2.49 ms with a shared tail).
-template <typename R, typename A, typename NodeT, int OUT, bool COUNT, bool SOFT, int NS>
+// Keeping the sit-out state as wave masks in scalar registers (sleeping lanes' masks on a small stack, pushed when
+// a cell is opened by some lanes and accepted by others) takes the vector instructions per visit from 17 to 13 and
+// adds nine scalar ones: 2.15 ms, no change.  Two bodies per lane behind one shared cursor (128 bodies per wave,
+// 0.58 times the visits, twice the arithmetic per visit): 2.57 ms.  Fetching the node with a vector load of eight
+// lanes and v_readlane instead of the scalar load: 2.9 ms.  The time scales with the waves resident per SIMD
+// (1, 2, 4, 8 waves: 10.2, 5.7, 3.2, 2.16 ms), i.e. one visit is a dependent chain of about 390 cycles (scalar load,
+// arithmetic, vote, branch) and eight waves, the hardware's limit, overlap it to about 80 cycles per visit and SIMD.
+template <typename R, typename A, typename NodeT, int OUT, bool COUNT, bool SOFT>
 __global__ __launch_bounds__(WALK_BLOCK) void walk_kernel(
     const NodeT* __restrict__ nodes, const int* __restrict__ counters, const typename V4<R>::type* __restrict__ posm,
     int t0, int t1, R theta, R floor2, A G, A dt, typename V4<A>::type* __restrict__ acc_out,
@@ -107,85 +135,75 @@ __global__ __launch_bounds__(WALK_BLOCK) void walk_kernel(
     // grid size; a placement assumption that only affects speed).
     const unsigned nwg = gridDim.x, q8 = nwg / 8, r8 = nwg % 8, xcd = blockIdx.x % 8;
     const unsigned wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + blockIdx.x / 8;
-    const int ibase = t0 + (int)wg * (WALK_BLOCK * NS) + threadIdx.x;
+    const int i = t0 + (int)wg * WALK_BLOCK + threadIdx.x;
     if (OUT == OUT_FUSED) {
         // bodies past n_alive (removed by the bound check) move to the next buffer unchanged
-#pragma unroll
-        for (int s = 0; s < NS; s++) {
-            const int i = ibase + s * WALK_BLOCK;
-            if (i >= tend && i < t1) {
-                pos_out[i] = pos_in[i];
-                vel_out[i] = vel_in[i];
-                if (mirror_out) { const A4 p = pos_in[i]; mirror_out[i] = make_float4((float)p.x, (float)p.y, (float)p.z, (float)p.w); }
-            }
+        if (i >= tend && i < t1) {
+            pos_out[i] = pos_in[i];
+            vel_out[i] = vel_in[i];
+            if (mirror_out) { const A4 p = pos_in[i]; mirror_out[i] = make_float4((float)p.x, (float)p.y, (float)p.z, (float)p.w); }
         }
     }
-    if (__ballot(ibase < tend) == 0) return;     // whole wave past the end (group 0 holds its lowest bodies)
+    const bool valid = i < tend;
+    if (__ballot(valid) == 0 || total <= 0) return;
 
-    bool valid[NS];
-    R px[NS], py[NS], pz[NS], fx[NS], fy[NS], fz[NS];
-    A ax[NS], ay[NS], az[NS], phi[NS];
-    int my_skip[NS];                             // the lane sits out while cursor < my_skip
-    int cur[NS];
+    R px = 0, py = 0, pz = 0, fx = 0, fy = 0, fz = 0;
+    if (valid) { const R4 p = posm[i]; px = p.x; py = p.y; pz = p.z; }
+    A ax = 0, ay = 0, az = 0, phi = 0;
+    int my_skip = valid ? 0 : 0x7fffffff;         // the lane sits out while cursor < my_skip
     unsigned count = 0;
-#pragma unroll
-    for (int s = 0; s < NS; s++) {
-        const int i = ibase + s * WALK_BLOCK;
-        valid[s] = i < tend;
-        px[s] = 0; py[s] = 0; pz[s] = 0;
-        if (valid[s]) { R4 p = posm[i]; px[s] = p.x; py[s] = p.y; pz[s] = p.z; }
-        fx[s] = 0; fy[s] = 0; fz[s] = 0; ax[s] = 0; ay[s] = 0; az[s] = 0; phi[s] = 0;
-        my_skip[s] = valid[s] ? 0 : 0x7fffffff;
-        cur[s] = __ballot(valid[s]) != 0 ? 0 : total;     // a group without bodies starts parked
-    }
     int it = 0;
-    // Cursors and the nodes under them live in scalar registers: one scalar load per visit and group.
+    // The cursor and the node under it live in scalar registers: one scalar load per visit.  A visit is a chain of
+    // dependent steps (load, distance, test, vote, next cursor), so the next node is requested as soon as the vote
+    // is in and the force arithmetic of the current node runs while that load is in flight; the record behind the
+    // last node (mass 0, skip = itself) makes the request past the end harmless.
     // (Fetching both possible successors ahead of the vote was slower: the scalar unit is shared by the CU's
     // four SIMDs, and the extra loads and selects cost more than the latency they hid.)
-    for (;;) {
-        if (NS == 1) {
-            if (cur[0] >= total) break;
-        } else {
-            bool more = false;
-#pragma unroll
-            for (int s = 0; s < NS; s++) more = more || cur[s] < total;
-            if (!more) break;
-        }
-#pragma unroll
-        for (int s = 0; s < NS; s++) {
-            const auto nd = load_raw(nodes, cur[s]);
-            const int skip = nd.skip;
-            const R dx = as_real(nd.x) - px[s], dy = as_real(nd.y) - py[s], dz = as_real(nd.z) - pz[s];
-            // The floor under r^2 (1e-12 m^2 unless softening is on) keeps rsq finite for the body's own leaf
-            // and for bodies at distance 0, which then contribute exactly 0 because dx = dy = dz = 0.
-            const R r2 = fma(dx, dx, fma(dy, dy, fma(dz, dz, floor2)));
-            const bool active = cur[s] >= my_skip[s];
-            // lanes sitting out get an infinite distance, so one compare is both the opening test and the vote
-            const R rtest = active ? (SOFT ? r2 - floor2 : r2) : (R)INFINITY;
-            const bool open = node_opens(nd, rtest, theta);
-            const bool take = active && !open;
-            if (take) my_skip[s] = skip;
-            const R rinv = rsq_dev(r2);
-            const R w = take ? (rinv * rinv) * (rinv * as_real(nd.m)) : (R)0;
-            fx[s] = fma(dx, w, fx[s]);
-            fy[s] = fma(dy, w, fy[s]);
-            fz[s] = fma(dz, w, fz[s]);
-            if (COUNT) {
-                const bool use = take && cur[s] < total && (dx != (R)0 || dy != (R)0 || dz != (R)0);
-                count += (unsigned)__popcll(__builtin_amdgcn_ballot_w64(use));
-                if (use) phi[s] += (A)(rinv * as_real(nd.m));
-            }
-            cur[s] = __builtin_amdgcn_ballot_w64(open) != 0 ? cur[s] + 1 : skip;
+    int cur = 0;
+    // One visit: consumes the record that `here` delivers, requests the successor into `there`.
+    auto visit = [&](auto& here, auto& there) -> bool {
+        const auto nd = arrived(here);
+        const int skip = nd.skip;
+        const R dx = as_real(nd.x) - px, dy = as_real(nd.y) - py, dz = as_real(nd.z) - pz;
+        // The floor under r^2 (1e-12 m^2 unless softening is on) keeps rsq finite for the body's own leaf
+        // and for bodies at distance 0, which then contribute exactly 0 because dx = dy = dz = 0.
+        R r2 = fma(dx, dx, fma(dy, dy, fma(dz, dz, floor2)));
+        const bool active = cur >= my_skip;
+        // lanes sitting out get an infinite distance, so one compare is both the opening test and the vote
+        const R rtest = active ? (SOFT ? r2 - floor2 : r2) : (R)INFINITY;
+        const bool open = node_opens(nd, rtest, theta);
+        const int next = __builtin_amdgcn_ballot_w64(open) != 0 ? cur + 1 : skip;
+        there = request_raw(nodes, next, r2);      // the force arithmetic below runs while this is in flight
+        const R mass = as_real(nd.m);
+        const bool take = active && !open;
+        if (take) my_skip = skip;
+        const R rinv = rsq_dev(r2);
+        const R w = take ? (rinv * rinv) * (rinv * mass) : (R)0;
+        fx = fma(dx, w, fx);
+        fy = fma(dy, w, fy);
+        fz = fma(dz, w, fz);
+        if (COUNT) {
+            const bool use = take && (dx != (R)0 || dy != (R)0 || dz != (R)0);
+            count += (unsigned)__popcll(__builtin_amdgcn_ballot_w64(use));
+            if (use) phi += (A)(rinv * mass);
         }
         ++it;
         if (BLOCKED && (it & 63) == 0) {
-#pragma unroll
-            for (int s = 0; s < NS; s++) {
-                ax[s] += (A)fx[s]; ay[s] += (A)fy[s]; az[s] += (A)fz[s];
-                fx[s] = 0; fy[s] = 0; fz[s] = 0;
-            }
+            ax += (A)fx; ay += (A)fy; az += (A)fz;
+            fx = 0; fy = 0; fz = 0;
         }
+        cur = next;
+        return next < total;
+    };
+    R none = 0;
+    auto slot_a = request_raw(nodes, 0, none);
+    decltype(slot_a) slot_b;
+    for (;;) {                                    // two record slots used in turn, so nothing is copied
+        if (!visit(slot_a, slot_b)) break;
+        if (!visit(slot_b, slot_a)) break;
     }
+    // the request left in flight must land before the wave ends or reuses those registers
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
     if (COUNT && (threadIdx.x & 63) == 0 && interactions) {
         atomicAdd(interactions, (unsigned long long)count);
@@ -196,25 +214,18 @@ __global__ __launch_bounds__(WALK_BLOCK) void walk_kernel(
         atomicAdd(interactions + 4 + (it >= 3000) + (it >= 4000) + (it >= 6000), 1ull);
 #endif
     }
-#pragma unroll
-    for (int s = 0; s < NS; s++) {
-        if (!valid[s]) continue;
-        const int i = ibase + s * WALK_BLOCK;
-        const A sx = ax[s] + (A)fx[s], sy = ay[s] + (A)fy[s], sz = az[s] + (A)fz[s];
-        if (OUT == OUT_ACC) {
-            A4 o; o.x = G * sx; o.y = G * sy; o.z = G * sz; o.w = phi[s];
-            acc_out[i] = o;
-        } else {
-            kick_drift<A>(i, G * sx, G * sy, G * sz, dt, pos_in, vel_in, pos_out, vel_out, mirror_out);
-        }
+    if (!valid) return;
+    const A sx = ax + (A)fx, sy = ay + (A)fy, sz = az + (A)fz;
+    if (OUT == OUT_ACC) {
+        A4 o; o.x = G * sx; o.y = G * sy; o.z = G * sz; o.w = phi;
+        acc_out[i] = o;
+    } else {
+        kick_drift<A>(i, G * sx, G * sy, G * sz, dt, pos_in, vel_in, pos_out, vel_out, mirror_out);
     }
 }
 
-#ifndef WALK_NS
-#define WALK_NS 1
-#endif
 #define WALK_LAUNCH(...)                                                                                     \
-    hipLaunchKernelGGL((soft ? walk_kernel<R, A, NodeT, __VA_ARGS__, true, WALK_NS> : walk_kernel<R, A, NodeT, __VA_ARGS__, false, WALK_NS>),
+    hipLaunchKernelGGL((soft ? walk_kernel<R, A, NodeT, __VA_ARGS__, true> : walk_kernel<R, A, NodeT, __VA_ARGS__, false>),
 
 template <typename R, typename A, typename NodeT>
 static int launch_walk(nbe_engine* e, const void* src, uint64_t t0, uint64_t t1, bool fused, bool count, int src_buf, int dst_buf)
@@ -234,7 +245,7 @@ static int launch_walk(nbe_engine* e, const void* src, uint64_t t0, uint64_t t1,
     A4* pos_out = (A4*)e->posm[dst_buf];
     A4* vel_out = (A4*)e->vel[dst_buf];
     float4* mirror_out = mixed ? e->mirror[dst_buf] : nullptr;
-    dim3 grid(cdiv(nt, WALK_BLOCK * WALK_NS));
+    dim3 grid(cdiv(nt, WALK_BLOCK));
     if (fused) {
         WALK_LAUNCH(OUT_FUSED, false) grid, dim3(WALK_BLOCK), 0, e->stream, (const NodeT*)e->tw.nodes,
                            e->tw.counters, (const R4*)src, (int)t0, (int)t1, (R)e->cfg.theta, floor2, G, dt, (A4*)e->acc,
