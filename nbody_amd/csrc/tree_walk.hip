@@ -41,7 +41,10 @@ __device__ __forceinline__ RawD load_raw(const NodeD* __restrict__ nodes, int i)
     return RawD{a.x, a.y, a.z, a.w, w.x, sk};
 }
 // The same request split in two: `request_raw` issues the load and returns at once, `arrived` waits for it.  The
-// compiler schedules a plain load next to its first use, which in the walk is one whole visit too late.
+// compiler schedules a plain load next to its first use, which in the walk is one whole visit too late (a plain
+// load held in place with a scheduling barrier works too, but costs register copies: 2.05 ms against 1.97 ms).
+// Between the two calls the destination registers are in flight and the compiler does not know it: the build
+// checks the device assembly for any instruction that touches them in that window (check_pending_sgprs.py).
 struct PendingF { unsigned v __attribute__((ext_vector_type(8))); };
 struct PendingD { RawD r; };
 // `after` is passed through a second statement that the compiler may not move ahead of the request: whatever is
@@ -115,6 +118,8 @@ __device__ __forceinline__ bool node_opens(const RawD& nd, double r2, double the
 // lanes and v_readlane instead of the scalar load: 2.9 ms.  The time scales with the waves resident per SIMD
 // (1, 2, 4, 8 waves: 10.2, 5.7, 3.2, 2.16 ms), i.e. one visit is a dependent chain of about 390 cycles (scalar load,
 // arithmetic, vote, branch) and eight waves, the hardware's limit, overlap it to about 80 cycles per visit and SIMD.
+// Shortening that chain is what helps: requesting the next node right after the vote, so that the force arithmetic
+// runs under the load, gives 1.97 ms (2.15 ms with the load at the top of the visit).
 template <typename R, typename A, typename NodeT, int OUT, bool COUNT, bool SOFT>
 __global__ __launch_bounds__(WALK_BLOCK) void walk_kernel(
     const NodeT* __restrict__ nodes, const int* __restrict__ counters, const typename V4<R>::type* __restrict__ posm,
