@@ -61,6 +61,8 @@ __device__ __forceinline__ RawF arrived(PendingF& p)
     asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(p.v));
     return RawF{p.v[0], p.v[1], p.v[2], p.v[3], p.v[4], (int)p.v[5]};
 }
+__device__ __forceinline__ void settle(PendingF& p) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(p.v)); }
+__device__ __forceinline__ void settle(PendingD&) {}
 __device__ __forceinline__ PendingD request_raw(const NodeD* __restrict__ nodes, int i, double&) { return PendingD{load_raw(nodes, i)}; }
 __device__ __forceinline__ RawD arrived(PendingD& p) { return p.r; }
 
@@ -156,6 +158,9 @@ __global__ __launch_bounds__(WALK_BLOCK) void walk_kernel(
     if (valid) { const R4 p = posm[i]; px = p.x; py = p.y; pz = p.z; }
     A ax = 0, ay = 0, az = 0, phi = 0;
     int my_skip = valid ? 0 : 0x7fffffff;         // the lane sits out while cursor < my_skip
+    // a vector instruction that reads a scalar register issues at half rate: keep the loop's constant in a vector one
+    R floor2v = floor2;
+    asm volatile("" : "+v"(floor2v));
     unsigned count = 0;
     int it = 0;
     // The cursor and the node under it live in scalar registers: one scalar load per visit.  A visit is a chain of
@@ -172,10 +177,10 @@ __global__ __launch_bounds__(WALK_BLOCK) void walk_kernel(
         const R dx = as_real(nd.x) - px, dy = as_real(nd.y) - py, dz = as_real(nd.z) - pz;
         // The floor under r^2 (1e-12 m^2 unless softening is on) keeps rsq finite for the body's own leaf
         // and for bodies at distance 0, which then contribute exactly 0 because dx = dy = dz = 0.
-        R r2 = fma(dx, dx, fma(dy, dy, fma(dz, dz, floor2)));
+        R r2 = fma(dx, dx, fma(dy, dy, fma(dz, dz, floor2v)));
         const bool active = cur >= my_skip;
         // lanes sitting out get an infinite distance, so one compare is both the opening test and the vote
-        const R rtest = active ? (SOFT ? r2 - floor2 : r2) : (R)INFINITY;
+        const R rtest = active ? (SOFT ? r2 - floor2v : r2) : (R)INFINITY;
         const bool open = node_opens(nd, rtest, theta);
         const int next = __builtin_amdgcn_ballot_w64(open) != 0 ? cur + 1 : skip;
         there = request_raw(nodes, next, r2);      // the force arithmetic below runs while this is in flight
@@ -183,7 +188,11 @@ __global__ __launch_bounds__(WALK_BLOCK) void walk_kernel(
         const bool take = active && !open;
         if (take) my_skip = skip;
         const R rinv = rsq_dev(r2);
-        const R w = take ? (rinv * rinv) * (rinv * mass) : (R)0;
+        R rinv2 = rinv * rinv;
+        // (keeps the compiler from pairing the two products in one packed multiply, for which it copies the mass
+        // to a vector register: one more instruction that reads a scalar register)
+        if (__is_same(R, float)) asm volatile("" : "+v"(rinv2));
+        const R w = take ? rinv2 * (rinv * mass) : (R)0;
         fx = fma(dx, w, fx);
         fy = fma(dy, w, fy);
         fz = fma(dz, w, fz);
@@ -198,7 +207,11 @@ __global__ __launch_bounds__(WALK_BLOCK) void walk_kernel(
             fx = 0; fy = 0; fz = 0;
         }
         cur = next;
-        return next < total;
+        if (next < total) return true;
+        // The record requested last is never read.  It still has to land before its registers may serve anything
+        // else: waiting here, with the slot as operand, keeps them reserved on the way out.
+        settle(there);
+        return false;
     };
     R none = 0;
     auto slot_a = request_raw(nodes, 0, none);
@@ -207,8 +220,7 @@ __global__ __launch_bounds__(WALK_BLOCK) void walk_kernel(
         if (!visit(slot_a, slot_b)) break;
         if (!visit(slot_b, slot_a)) break;
     }
-    // the request left in flight must land before the wave ends or reuses those registers
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // nothing is in flight here; states it on every path out of the loop
 
     if (COUNT && (threadIdx.x & 63) == 0 && interactions) {
         atomicAdd(interactions, (unsigned long long)count);
