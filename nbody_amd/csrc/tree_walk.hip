@@ -115,13 +115,19 @@ __device__ __forceinline__ bool node_opens(const RawD& nd, double r2, double the
 // register copies and mask bookkeeping at the join (2.21 ms with both arms written out, 2.49 ms with a shared tail).
 // Keeping the sit-out state as wave masks in scalar registers (sleeping lanes' masks on a small stack, pushed when
 // a cell is opened by some lanes and accepted by others) takes the vector instructions per visit from 17 to 13 and
-// adds nine scalar ones: 2.15 ms, no change.  Two bodies per lane behind one shared cursor (128 bodies per wave,
+// adds nine scalar ones: 2.15 ms, no change (2.8 ms when combined with the early request described below: its
+// pushes and pops are branches inside the visit).  Two bodies per lane behind one shared cursor (128 bodies per wave,
 // 0.58 times the visits, twice the arithmetic per visit): 2.57 ms.  Fetching the node with a vector load of eight
 // lanes and v_readlane instead of the scalar load: 2.9 ms.  The time scales with the waves resident per SIMD
 // (1, 2, 4, 8 waves: 10.2, 5.7, 3.2, 2.16 ms), i.e. one visit is a dependent chain of about 390 cycles (scalar load,
 // arithmetic, vote, branch) and eight waves, the hardware's limit, overlap it to about 80 cycles per visit and SIMD.
 // Shortening that chain is what helps: requesting the next node right after the vote, so that the force arithmetic
-// runs under the load, gives 1.97 ms (2.15 ms with the load at the top of the visit).
+// runs under the load, gives 1.97 ms (2.15 ms with the load at the top of the visit).  After that the visit is
+// bound by instruction issue, where a vector instruction costs twice as much when it reads a scalar register:
+// moving the loop's constant to a vector register and not letting the compiler pair the two products (which
+// needs the mass copied to a vector register) gives 1.84 ms.  Testing for the end once per two visits lets the
+// compiler interleave the two and wait too early (1.87 ms); taking the vote from the plain compare and masking
+// sleeping lanes with scalar logic instead of the select makes it rebuild the masks through vector registers.
 template <typename R, typename A, typename NodeT, int OUT, bool COUNT, bool SOFT>
 __global__ __launch_bounds__(WALK_BLOCK) void walk_kernel(
     const NodeT* __restrict__ nodes, const int* __restrict__ counters, const typename V4<R>::type* __restrict__ posm,
