@@ -289,6 +289,17 @@ def main():
             if headline_mode == "tree":
                 cpu = {"value": tb["interactions_per_s"], "unit": "interactions/s", "cores": 4, "kind": "port", "sample": tb["sample"]}
             extra["cpu_tree_path_1M"] = tb
+            # the same pass with one walk thread per core of this job's CPU share (the reference is fixed at four)
+            cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
+            from nbody_amd import physics as _ph
+            from oracle import oracle as O
+            b = _ph.plummer(1 << 20, seed=1)
+            t0 = time.perf_counter()
+            _, _, st = O.forces(b.mass, b.pos, mode="tree", com_mode="true", theta=0.5, drop_tail=False, groups=cores)
+            dt_all = time.perf_counter() - t0
+            extra["cpu_tree_path_1M_all_cores"] = {"steps_per_s": 1.0 / dt_all, "interactions_per_s": st.interactions / dt_all,
+                                                   "cores": cores, "kind": "port", "build_s": st.build_seconds, "walk_s": st.walk_seconds,
+                                                   "sample": f"as cpu_tree_path_1M with {cores} walk threads instead of the reference's 4"}
         except Exception as ex:  # the baseline must never take the benchmark down
             log("cpu tree baseline failed:", ex)
 
