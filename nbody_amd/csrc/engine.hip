@@ -89,7 +89,13 @@ extern "C" int nbe_create(const nbe_config* cfg, nbe_engine** out)
     }
     for (int k = 0; k < 5 && rc == NBE_OK; k++)
         if (hipEventCreate(&e->ev[k]) != hipSuccess) { nbe_set_error("hipEventCreate failed"); rc = NBE_E_DEVICE; }
-    if (rc != NBE_OK) { delete e; return rc; }
+    if (rc != NBE_OK) {
+        for (int k = 0; k < 5; k++)
+            if (e->ev[k]) (void)hipEventDestroy(e->ev[k]);
+        if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
+        delete e;
+        return rc;
+    }
     e->stream = e->own_stream;
     *out = e;
     return NBE_OK;
@@ -135,7 +141,9 @@ extern "C" int nbe_upload(nbe_engine* e, size_t n, const double* pos, const doub
     if (e->cfg.mode == NBE_MODE_TREE && n > (1ull << 26)) { nbe_set_error("tree mode supports at most 2^26 bodies"); return NBE_E_UNSUPPORTED; }
     for (size_t i = 0; i < n; i++)
         if (!(mass[i] >= 0.0)) { nbe_set_error("mass[%zu] is negative or NaN", i); return NBE_E_INVALID; }
-    const int rc = upload_state(e, n, pos, vel, mass, id);
+    int rc;
+    try { rc = upload_state(e, n, pos, vel, mass, id); }
+    catch (const std::bad_alloc&) { nbe_set_error("out of host memory"); rc = NBE_E_NOMEM; }
     if (rc != NBE_OK) {
         // leave an empty engine behind rather than half of a state (the message of the failure is kept)
         char msg[512];
@@ -283,7 +291,7 @@ static int live_slots(nbe_engine* e, std::vector<uint32_t>* slot_of, size_t* n_a
     return NBE_OK;
 }
 
-extern "C" int nbe_download(nbe_engine* e, double* pos, double* vel, double* mass, uint64_t* id, size_t* n_alive_out)
+static int download_impl(nbe_engine* e, double* pos, double* vel, double* mass, uint64_t* id, size_t* n_alive_out)
 {
     if (!e) { nbe_set_error("engine is NULL"); return NBE_E_INVALID; }
     NBE_TRY(use_device(e));
@@ -321,7 +329,7 @@ extern "C" int nbe_download(nbe_engine* e, double* pos, double* vel, double* mas
     return NBE_OK;
 }
 
-extern "C" int nbe_set_radius(nbe_engine* e, const double* radius)
+static int set_radius_impl(nbe_engine* e, const double* radius)
 {
     if (!e) { nbe_set_error("engine is NULL"); return NBE_E_INVALID; }
     if (!e->cfg.collisions) { nbe_set_error("nbe_set_radius needs an engine created with collisions on"); return NBE_E_INVALID; }
@@ -340,7 +348,7 @@ extern "C" int nbe_set_radius(nbe_engine* e, const double* radius)
     return NBE_OK;
 }
 
-extern "C" int nbe_get_radius(nbe_engine* e, double* radius, size_t* n_alive_out)
+static int get_radius_impl(nbe_engine* e, double* radius, size_t* n_alive_out)
 {
     if (!e) { nbe_set_error("engine is NULL"); return NBE_E_INVALID; }
     if (!e->cfg.collisions) { nbe_set_error("nbe_get_radius needs an engine created with collisions on"); return NBE_E_INVALID; }
@@ -565,7 +573,7 @@ extern "C" int nbe_stats(nbe_engine* e, nbe_stats_t* stats)
     return NBE_OK;
 }
 
-extern "C" int nbe_accel(nbe_engine* e, double* acc_xyz, uint8_t* alive_out)
+static int accel_impl(nbe_engine* e, double* acc_xyz, uint8_t* alive_out)
 {
     if (!e) { nbe_set_error("engine is NULL"); return NBE_E_INVALID; }
     NBE_TRY(use_device(e));
@@ -628,7 +636,7 @@ extern "C" int nbe_time_force_kernel(nbe_engine* e, int reps, float* ms_per_laun
     return NBE_OK;
 }
 
-extern "C" int nbe_tree_nodes(nbe_engine* e, double* out, size_t cap, size_t* count)
+static int tree_nodes_impl(nbe_engine* e, double* out, size_t cap, size_t* count)
 {
     if (!e || !count) { nbe_set_error("NULL argument"); return NBE_E_INVALID; }
     NBE_TRY(use_device(e));
@@ -662,3 +670,15 @@ extern "C" int nbe_tree_nodes(nbe_engine* e, double* out, size_t cap, size_t* co
     }
     return NBE_OK;
 }
+
+// Entry points that build host-side arrays of n elements: running out of host memory is reported, not thrown across
+// the C boundary.
+#define NBE_GUARDED(call)                                                                \
+    try { return (call); }                                                               \
+    catch (const std::bad_alloc&) { nbe_set_error("out of host memory"); return NBE_E_NOMEM; }
+
+extern "C" int nbe_download(nbe_engine* e, double* pos, double* vel, double* mass, uint64_t* id, size_t* n_alive_out) { NBE_GUARDED(download_impl(e, pos, vel, mass, id, n_alive_out)) }
+extern "C" int nbe_set_radius(nbe_engine* e, const double* radius) { NBE_GUARDED(set_radius_impl(e, radius)) }
+extern "C" int nbe_get_radius(nbe_engine* e, double* radius, size_t* n_alive_out) { NBE_GUARDED(get_radius_impl(e, radius, n_alive_out)) }
+extern "C" int nbe_accel(nbe_engine* e, double* acc_xyz, uint8_t* alive_out) { NBE_GUARDED(accel_impl(e, acc_xyz, alive_out)) }
+extern "C" int nbe_tree_nodes(nbe_engine* e, double* out, size_t cap, size_t* count) { NBE_GUARDED(tree_nodes_impl(e, out, cap, count)) }

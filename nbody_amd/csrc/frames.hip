@@ -78,18 +78,35 @@ static void delivery_loop(nbe_engine* e)
     }
 }
 
-extern "C" int nbe_frame_stream_begin(nbe_engine* e, int every, int slots, int first_frame, nbe_frame_cb cb, void* user)
+// Frees whatever frame_stream_allocate set up (every pointer is tested, so a partial set-up is fine).
+static void frame_stream_release(nbe_engine* e)
 {
-    if (!e || !cb) { nbe_set_error("nbe_frame_stream_begin: NULL argument"); return NBE_E_INVALID; }
-    if (every < 1 || slots < 1 || slots > 1024) { nbe_set_error("every must be >= 1 and slots in 1..1024"); return NBE_E_INVALID; }
-    if (e->fs.active) { nbe_set_error("frame streaming is already on"); return NBE_E_INVALID; }
-    NBE_HIP(hipSetDevice(e->cfg.device));
+    FrameStream& fs = e->fs;
+    (void)hipSetDevice(e->cfg.device);
+    if (fs.side) (void)hipStreamSynchronize(fs.side);
+    for (FrameSlot& s : fs.slots) {
+        if (s.xyzm) (void)hipHostFree(s.xyzm);
+        if (s.orig) (void)hipHostFree(s.orig);
+        if (s.radius) (void)hipHostFree(s.radius);
+        if (s.dead) (void)hipHostFree(s.dead);
+        if (s.n_alive) (void)hipHostFree(s.n_alive);
+        if (s.d_n_alive) (void)hipFree(s.d_n_alive);
+        if (s.done) (void)hipEventDestroy(s.done);
+    }
+    fs.slots.clear();
+    if (fs.staging) { (void)hipFree(fs.staging); fs.staging = nullptr; }
+    if (fs.radius_staging) { (void)hipFree(fs.radius_staging); fs.radius_staging = nullptr; }
+    if (fs.state_ready) { (void)hipEventDestroy(fs.state_ready); fs.state_ready = nullptr; }
+    for (int b = 0; b < 2; b++)
+        if (fs.copy_done[b]) { (void)hipEventDestroy(fs.copy_done[b]); fs.copy_done[b] = nullptr; }
+    if (fs.side) { (void)hipStreamDestroy(fs.side); fs.side = nullptr; }
+    fs.copy_pending[0] = fs.copy_pending[1] = false;
+}
+
+static int frame_stream_allocate(nbe_engine* e, int slots)
+{
     FrameStream& fs = e->fs;
     const size_t cap = e->n > 0 ? e->n : 1;
-    fs.every = every; fs.first_frame = first_frame; fs.cb = cb; fs.user = user;
-    fs.step_base = e->stats.steps;
-    fs.stop = false; fs.copy_pending[0] = fs.copy_pending[1] = false;
-    fs.queue.clear();
     NBE_HIP(hipStreamCreateWithFlags(&fs.side, hipStreamNonBlocking));
     NBE_HIP(hipEventCreateWithFlags(&fs.state_ready, hipEventDisableTiming));
     NBE_HIP(hipEventCreateWithFlags(&fs.copy_done[0], hipEventDisableTiming));
@@ -106,9 +123,36 @@ extern "C" int nbe_frame_stream_begin(nbe_engine* e, int every, int slots, int f
         NBE_HIP(hipMalloc((void**)&s.d_n_alive, sizeof(int)));
         NBE_HIP(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
     }
-    fs.active = true;
-    fs.worker = std::thread(delivery_loop, e);
     return NBE_OK;
+}
+
+extern "C" int nbe_frame_stream_begin(nbe_engine* e, int every, int slots, int first_frame, nbe_frame_cb cb, void* user)
+{
+    if (!e || !cb) { nbe_set_error("nbe_frame_stream_begin: NULL argument"); return NBE_E_INVALID; }
+    if (every < 1 || slots < 1 || slots > 1024) { nbe_set_error("every must be >= 1 and slots in 1..1024"); return NBE_E_INVALID; }
+    if (e->fs.active) { nbe_set_error("frame streaming is already on"); return NBE_E_INVALID; }
+    NBE_HIP(hipSetDevice(e->cfg.device));
+    FrameStream& fs = e->fs;
+    fs.every = every; fs.first_frame = first_frame; fs.cb = cb; fs.user = user;
+    fs.step_base = e->stats.steps;
+    fs.stop = false; fs.copy_pending[0] = fs.copy_pending[1] = false;
+    fs.queue.clear();
+    int rc;
+    try {
+        rc = frame_stream_allocate(e, slots);
+        if (rc == NBE_OK) {
+            fs.active = true;
+            fs.worker = std::thread(delivery_loop, e);
+        }
+    } catch (const std::exception& ex) {
+        nbe_set_error("frame streaming could not start: %s", ex.what());
+        rc = NBE_E_NOMEM;
+    }
+    if (rc != NBE_OK) {                            // keep the message of the failure, drop what was set up
+        fs.active = false;
+        frame_stream_release(e);
+    }
+    return rc;
 }
 
 // Called before any kernel that writes state buffer `buf`: if a frame copy is still reading that buffer, the
@@ -193,25 +237,7 @@ int frame_stream_stop(nbe_engine* e)
     }
     fs.cv_work.notify_all();
     if (fs.worker.joinable()) fs.worker.join();      // delivers everything still queued first
-    (void)hipSetDevice(e->cfg.device);
-    (void)hipStreamSynchronize(fs.side);
-    for (FrameSlot& s : fs.slots) {
-        if (s.xyzm) (void)hipHostFree(s.xyzm);
-        if (s.orig) (void)hipHostFree(s.orig);
-        if (s.radius) (void)hipHostFree(s.radius);
-        if (s.dead) (void)hipHostFree(s.dead);
-        if (s.n_alive) (void)hipHostFree(s.n_alive);
-        if (s.d_n_alive) (void)hipFree(s.d_n_alive);
-        if (s.done) (void)hipEventDestroy(s.done);
-    }
-    fs.slots.clear();
-    if (fs.staging) { (void)hipFree(fs.staging); fs.staging = nullptr; }
-    if (fs.radius_staging) { (void)hipFree(fs.radius_staging); fs.radius_staging = nullptr; }
-    if (fs.state_ready) { (void)hipEventDestroy(fs.state_ready); fs.state_ready = nullptr; }
-    for (int b = 0; b < 2; b++)
-        if (fs.copy_done[b]) { (void)hipEventDestroy(fs.copy_done[b]); fs.copy_done[b] = nullptr; }
-    if (fs.side) { (void)hipStreamDestroy(fs.side); fs.side = nullptr; }
-    fs.copy_pending[0] = fs.copy_pending[1] = false;
+    frame_stream_release(e);
     fs.active = false;
     return NBE_OK;
 }
