@@ -11,7 +11,8 @@
 // The step itself (main.go:104-178) is one nbe_step call, collisions included: in tree mode the search, queue and
 // merge of tree.go:245-281 / main.go:151-167, in the direct sum the merge inside the pair sweep (main.go:122-126).
 // The reference's sinks are a PNG renderer, a gob chunk store and sqlite; the sink here writes the record the
-// gob store keeps per body (gob.go:54-61: X, Y, Z, Mass, Radius as float32, keyed by ID) as raw binary frames.
+// gob store keeps per body (gob.go:54-61: X, Y, Z, Mass, Radius as float32, keyed by ID) as raw binary frames;
+// `python -m nbody_amd.render DIR` turns those into the images of render.go.
 #include <chrono>
 #include <cmath>
 #include <condition_variable>

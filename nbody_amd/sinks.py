@@ -3,7 +3,7 @@
 `SqliteSink` writes the database of database.go: same table, same column order, same rounding, one transaction
 per frame, indices created at the end.  `ChunkSink` is the chunked, zlib-compressed gob store of gob.go (written
 from the encoding/gob specification; no Go exists here to read the files back, so that format is unpinned).
-The reference's third sink, the PNG renderer (render.go), is not rebuilt.
+The reference's default sink, the PNG renderer (render.go), is in render.py.
 """
 import glob
 import os
