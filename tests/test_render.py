@@ -37,6 +37,19 @@ def test_film_equals_scalar_restatement(frame, seed, size):
     assert (film[:, :, :3].reshape(-1, 3).any(axis=1)).sum() > 50      # something was drawn
 
 
+@pytest.mark.parametrize("seed", [21, 22, 23])
+def test_film_equals_restatement_with_bodies_everywhere(seed):
+    """Bodies far outside the bound: behind the camera (w <= 0), left and right of the image (the depth index then
+    names a cell of the neighbouring row), above and below it, and coincident ones."""
+    b = scene(600, seed, spread=40000.0)
+    b[10] = b[11]                                # coincident bodies: equal depth, the later one stays
+    b[12, :3] = b[0, :3]                         # on top of a light
+    frame = 100 * seed
+    film = render.render_frame(frame, b, 96, 54, labels=False)
+    ref, _ = oracle_film(frame, b, 96, 54)
+    assert np.array_equal(film, ref)
+
+
 def test_camera_matches_restatement_bitwise():
     b = scene(10, 5)
     for frame in (0, 1, 359, 1440, 8760):
