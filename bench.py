@@ -242,6 +242,14 @@ def main():
         s5 = timed_steps(lambda: e5.step(1), sync, barrier, 10, 100)
         extra["default_scene_1002_tree_theta1"] = {"gpu_ms_per_step": 1e3 * s5 / 100}
         e5.close()
+        # the same scene with the Go program's own arithmetic (running cell centres, last n mod 4 bodies unwalked):
+        # what the CPU port below computes, number for number
+        e5 = Engine(mode="tree", precision="f64", theta=1.0, device=local, ref_com=True, drop_tail=True)
+        e5.upload(g.pos, g.vel, g.mass)
+        e5.set_stream(torch.cuda.current_stream().cuda_stream)
+        s5 = timed_steps(lambda: e5.step(1), sync, barrier, 10, 100)
+        extra["default_scene_1002_tree_theta1"]["gpu_ms_per_step_reference_quirks_fp64"] = 1e3 * s5 / 100
+        e5.close()
         if rank == 0 and not args.no_cpu_baseline:
             from oracle import oracle as O
             t0 = time.perf_counter()

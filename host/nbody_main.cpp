@@ -2,7 +2,7 @@
 //
 // The reference is a Go program; no Go toolchain exists where this was written, so the host side is C++ with the
 // reference's flags, its body type, its initial-condition generator and its frame loop:
-//   flags           main.go:17-24   -n -y -state -save -tree -norender -nocollision   (+ -seed -theta -frames-dir)
+//   flags           main.go:17-24   -n -y -state -save -tree -norender -nocollision   (+ -seed -theta -frames-dir -asgo)
 //   makebodies      physics.go:16-73 with the two cores of main.go:35-36
 //   frame loop      main.go:80-190  (frames+1 iterations; a frame copy goes to the workers BEFORE each step)
 //   output workers  main.go:50-61   4 consumers behind a queue of capacity 32 (here fed by nbe_frame_stream_begin)
@@ -236,7 +236,7 @@ int main(int argc, char** argv)
     int numbodies = 10;
     double years = 1;
     std::string stateFilename, framesDir = "frames";
-    bool stateSave = false, tree = false, norender = false, nocollision = false;
+    bool stateSave = false, tree = false, norender = false, nocollision = false, asgo = false;
     uint64_t seed = 1;
     double theta = 1;                                        // main.go:73
     int precision = NBE_PREC_F32;
@@ -261,6 +261,7 @@ int main(int argc, char** argv)
         else if (a == "-tree") tree = true;
         else if (a == "-norender") norender = true;
         else if (a == "-nocollision") nocollision = true;
+        else if (a == "-asgo") asgo = true;
         else panic("flag provided but not defined: " + a);
     }
 
@@ -302,6 +303,9 @@ int main(int argc, char** argv)
     cfg.dt = dt;
     cfg.precision = precision;
     cfg.collisions = nocollision ? 0 : 1;                    // main.go:24
+    // -asgo: the tree path with the Go program's own arithmetic (running cell centres tree.go:189-193, last
+    // n mod 4 bodies unwalked main.go:134-148), for comparing a run with the reference number for number
+    if (asgo && tree) cfg.reference_quirks = NBE_QUIRK_REF_COM | NBE_QUIRK_DROP_TAIL;
     nbe_engine* eng = nullptr;
     check(nbe_create(&cfg, &eng));
     const size_t n = bodies.size();

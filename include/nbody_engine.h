@@ -50,7 +50,18 @@ typedef struct {
     int device;             /* HIP device ordinal */
     int collisions;         /* 0 = the `-nocollision` run (main.go:24); 1 = bodies that touch merge (tree mode:
                                tree.go:245-281 + main.go:151-167; direct sum: main.go:122-126; physics.go:153-162) */
+    int reference_quirks;   /* tree mode: bit set of NBE_QUIRK_*; 0 = physically meant behaviour */
 } nbe_config;
+
+/* Two things the reference's tree path does that a gravity solver would not, reproduced on request so that a run
+ * can be compared with the Go program number for number (both are off by default):
+ *   NBE_QUIRK_REF_COM    a cell's "centre of mass" is the running value of tree.go:189-193,
+ *                        com += p * (m / totalMass) in insertion (upload) order, which never rescales the old value:
+ *                        com = p_1 + sum_{k>=2} p_k * m_k / (m_1 + ... + m_k).  Computed serially per cell, so
+ *                        the build is slow for large scenes (the cell of all n bodies is one chain of n steps).
+ *   NBE_QUIRK_DROP_TAIL  the walk covers 4 * (n / 4) bodies (main.go:134-148): the last n mod 4 bodies of the
+ *                        upload order feel no force but are still integrated. */
+enum { NBE_QUIRK_REF_COM = 1, NBE_QUIRK_DROP_TAIL = 2 };
 
 typedef struct {
     uint64_t n, n_alive;

@@ -65,6 +65,8 @@ extern "C" int nbe_create(const nbe_config* cfg, nbe_engine** out)
     if (cfg->precision < NBE_PREC_F32 || cfg->precision > NBE_PREC_F64) { nbe_set_error("bad precision %d", cfg->precision); return NBE_E_INVALID; }
     if (!(cfg->bound_width > 0) || !(cfg->theta >= 0) || !(cfg->eps >= 0)) { nbe_set_error("bound_width must be > 0, theta and eps >= 0"); return NBE_E_INVALID; }
     if (cfg->collisions != 0 && cfg->collisions != 1) { nbe_set_error("collisions must be 0 or 1"); return NBE_E_INVALID; }
+    if (cfg->reference_quirks & ~(NBE_QUIRK_REF_COM | NBE_QUIRK_DROP_TAIL)) { nbe_set_error("unknown bit in reference_quirks"); return NBE_E_INVALID; }
+    if (cfg->reference_quirks && cfg->mode != NBE_MODE_TREE) { nbe_set_error("reference_quirks apply to tree mode only"); return NBE_E_INVALID; }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
         nbe_set_error("no HIP device available (this library has no CPU path)");

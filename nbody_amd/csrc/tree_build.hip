@@ -715,6 +715,127 @@ __global__ __launch_bounds__(256) void cell_mass_kernel(const int* __restrict__ 
     nodes[p].m = m;
 }
 
+
+// ---- the reference's running "centre of mass" (NBE_QUIRK_REF_COM) -------------------------------------------
+// tree.go:156-160 gives a new leaf its body's position and mass; tree.go:189-193 then updates a cell for every
+// later body that lands in it with  totalMass += m;  com = com + p * (m / totalMass)  and never rescales the old
+// value.  Bodies are pushed in slice order (tree.go:287-293), so a cell's value is that recurrence over its
+// bodies in upload order, whatever its depth (a cell that starts as a leaf and splits keeps its values,
+// tree.go:170-177).  One-child chains, which this tree does not materialise, hold the same bodies in the same
+// order as the branching cell below them and therefore the same value.  The arithmetic is kept literally (one
+// rounding per operation, no contraction) so that fp64 node records equal the Go program's bit for bit.
+struct RefCom { double M, x, y, z; bool any; };
+
+// Value of lane `src` (wave-uniform index) for every lane, through scalar registers: v_readlane_b32 instead of the
+// LDS crossbar of __shfl, whose latency would be paid once per body in the serial loops below.
+__device__ __forceinline__ double lane_value(double v, int src)
+{
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)bits, src);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(bits >> 32), src);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+// Applies the recurrence to the bodies held by the lanes of `mask`, in ascending lane order.  Only the additions
+// are serial (running mass, then running centre); the division and the products of all lanes run side by side in
+// between, which leaves every intermediate value exactly as the one-body-at-a-time loop rounds it.
+__device__ __forceinline__ void ref_com_push_lanes(RefCom& c, unsigned long long mask, double pm, double px, double py, double pz)
+{
+#pragma clang fp contract(off)
+    const int lane = threadIdx.x & 63;
+    if (mask == 0) return;
+    if (!c.any) {                                    // tree.go:156-160: the first body's position and mass
+        const int src = __ffsll(mask) - 1;
+        mask &= mask - 1;
+        c.any = true;
+        c.M = lane_value(pm, src); c.x = lane_value(px, src); c.y = lane_value(py, src); c.z = lane_value(pz, src);
+    }
+    double my_total = 1.0;
+    for (unsigned long long m = mask; m; m &= m - 1) {            // tree.go:191
+        const int src = __ffsll(m) - 1;
+        c.M = c.M + lane_value(pm, src);
+        if (lane == src) my_total = c.M;
+    }
+    const double s = pm / my_total;                               // tree.go:192, b.Mass / n.totalMass
+    const double tx = px * s, ty = py * s, tz = pz * s;
+    for (unsigned long long m = mask; m; m &= m - 1) {
+        const int src = __ffsll(m) - 1;
+        c.x = c.x + lane_value(tx, src); c.y = c.y + lane_value(ty, src); c.z = c.z + lane_value(tz, src);
+    }
+}
+
+// inv[upload index] = sorted index of a live body; 0xffffffff for bodies outside the bound.
+__global__ __launch_bounds__(256) void ref_inv_kernel(const int* __restrict__ counters, const uint32_t* __restrict__ orig,
+                                                      uint32_t* __restrict__ inv)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < counters[0]) inv[orig[i]] = (uint32_t)i;
+}
+
+// One wave per binary radix-tree node; those that are octree cells overwrite the node's mass and centre.
+// A cell of at most 64 bodies ranks its members by upload index inside the wave; a larger one scans the upload
+// order 64 indices at a time (inv tells whether an index lies in the cell's sorted range) and takes the hits in
+// ascending order.  Either way the recurrence itself is serial: the cell of all n bodies is a chain of n steps.
+template <typename R4, typename NodeT>
+__global__ __launch_bounds__(256) void ref_com_kernel(int n, const int* __restrict__ counters, const R4* __restrict__ posm,
+                                                      const uint32_t* __restrict__ orig, const uint32_t* __restrict__ inv,
+                                                      const int* __restrict__ bt_first, const int* __restrict__ bt_last,
+                                                      const int* __restrict__ bt_parent, const uint8_t* __restrict__ bt_level,
+                                                      const uint32_t* __restrict__ lvlmask, const uint32_t* __restrict__ cellcnt,
+                                                      NodeT* __restrict__ nodes)
+{
+    const int na = counters[0];
+    const int i = (int)((blockIdx.x * 256u + threadIdx.x) >> 6);
+    const int lane = threadIdx.x & 63;
+    if (i >= na - 1) return;
+    const int par = bt_parent[i];
+    const int lvl = bt_level[i];
+    if (!(par < 0 || bt_level[par] != lvl)) return;
+    const int a = bt_first[i], b = bt_last[i];
+    const int c = b - a + 1;
+    const int pos = a + (int)cellcnt[a] + __popc(lvlmask[a] & ((1u << lvl) - 1u));
+    RefCom acc{0, 0, 0, 0, false};
+    if (c <= 64) {
+        const bool have = lane < c;
+        const uint32_t o = have ? orig[a + lane] : 0xffffffffu;
+        double pm = 0, px = 0, py = 0, pz = 0;
+        if (have) { const R4 p = posm[a + lane]; pm = (double)p.w; px = (double)p.x; py = (double)p.y; pz = (double)p.z; }
+        int rank = 0;
+        for (int k = 0; k < c; k++) rank += (__shfl(o, k, 64) < o) ? 1 : 0;
+        // lane r takes the member of rank r, so lane order is upload order
+        int from = 0;
+        for (int k = 0; k < c; k++) { const int rk = __shfl(rank, k, 64); if (rk == lane) from = k; }
+        pm = __shfl(pm, from, 64); px = __shfl(px, from, 64); py = __shfl(py, from, 64); pz = __shfl(pz, from, 64);
+        ref_com_push_lanes(acc, c == 64 ? ~0ull : (1ull << c) - 1ull, pm, px, py, pz);
+    } else {
+        // REF_UNROLL chunks of 64 upload indices per round, so that their loads are in flight together (one round
+        // is two dependent memory latencies: the index, then the hits' bodies)
+        constexpr int REF_UNROLL = 8;
+        for (int u0 = 0; u0 < n; u0 += 64 * REF_UNROLL) {
+            uint32_t s[REF_UNROLL];
+#pragma unroll
+            for (int k = 0; k < REF_UNROLL; k++) {
+                const int u = u0 + 64 * k + lane;
+                s[k] = u < n ? inv[u] : 0xffffffffu;
+            }
+            bool hit[REF_UNROLL];
+            double pm[REF_UNROLL], px[REF_UNROLL], py[REF_UNROLL], pz[REF_UNROLL];
+#pragma unroll
+            for (int k = 0; k < REF_UNROLL; k++) {
+                hit[k] = s[k] >= (uint32_t)a && s[k] <= (uint32_t)b;
+                pm[k] = 0; px[k] = 0; py[k] = 0; pz[k] = 0;
+                if (hit[k]) { const R4 p = posm[s[k]]; pm[k] = (double)p.w; px[k] = (double)p.x; py[k] = (double)p.y; pz[k] = (double)p.z; }
+            }
+#pragma unroll
+            for (int k = 0; k < REF_UNROLL; k++)
+                ref_com_push_lanes(acc, (unsigned long long)__ballot(hit[k]), pm[k], px[k], py[k], pz[k]);
+        }
+    }
+    if (lane == 0) {
+        nodes[pos].x = acc.x; nodes[pos].y = acc.y; nodes[pos].z = acc.z; nodes[pos].m = acc.M;
+    }
+}
+
 // ---- host side ---------------------------------------------------------------------------------------------
 static int free_ptr(void** p)
 {
@@ -867,6 +988,16 @@ static int sort_and_build_t(nbe_engine* e)
             hipLaunchKernelGGL((cell_mass_kernel<NodeT>), dim3(cdiv(2 * (size_t)n, 256)), dim3(256), 0, e->stream, w.counters,
                                level, (NodeT*)w.nodes, w.node_level, w.node_sum);
         }
+        NBE_HIP(hipGetLastError());
+    }
+    if (e->cfg.reference_quirks & NBE_QUIRK_REF_COM) {
+        // the sort's second index buffer is free between sorts: it holds the inverse of the sorted order here
+        uint32_t* inv = w.sidx[1];
+        NBE_HIP(hipMemsetAsync(inv, 0xff, (size_t)n * 4, e->stream));
+        hipLaunchKernelGGL(ref_inv_kernel, dim3(nb), dim3(256), 0, e->stream, w.counters, e->orig[e->orig_cur], inv);
+        hipLaunchKernelGGL((ref_com_kernel<R4, NodeT>), dim3(cdiv((size_t)n * 64, 256)), dim3(256), 0, e->stream, n, w.counters,
+                           sorted_pos, e->orig[e->orig_cur], inv, w.bt_first, w.bt_last, w.bt_parent, w.bt_level, w.lvlmask,
+                           w.cellcnt, (NodeT*)w.nodes);
         NBE_HIP(hipGetLastError());
     }
     if (e->cfg.collisions) NBE_TRY(collide_emit_nodes(e));

@@ -134,7 +134,8 @@ __global__ __launch_bounds__(WALK_BLOCK) void walk_kernel(
     int t0, int t1, R theta, R floor2, A G, A dt, typename V4<A>::type* __restrict__ acc_out,
     const typename V4<A>::type* __restrict__ pos_in, const typename V4<A>::type* __restrict__ vel_in,
     typename V4<A>::type* __restrict__ pos_out, typename V4<A>::type* __restrict__ vel_out,
-    float4* __restrict__ mirror_out, unsigned long long* __restrict__ interactions)
+    float4* __restrict__ mirror_out, unsigned long long* __restrict__ interactions,
+    const uint32_t* __restrict__ tail_orig, unsigned tail_limit)
 {
     using R4 = typename V4<R>::type;
     using A4 = typename V4<A>::type;
@@ -163,7 +164,10 @@ __global__ __launch_bounds__(WALK_BLOCK) void walk_kernel(
     R px = 0, py = 0, pz = 0, fx = 0, fy = 0, fz = 0;
     if (valid) { const R4 p = posm[i]; px = p.x; py = p.y; pz = p.z; }
     A ax = 0, ay = 0, az = 0, phi = 0;
-    int my_skip = valid ? 0 : 0x7fffffff;         // the lane sits out while cursor < my_skip
+    // tail_orig (NBE_QUIRK_DROP_TAIL): bodies whose upload index is tail_limit or more are not walked, like the
+    // last n mod 4 bodies of main.go:134-148; they sit out the whole traversal and are integrated with zero force
+    const bool walked = valid && !(tail_orig && tail_orig[i] >= tail_limit);
+    int my_skip = walked ? 0 : 0x7fffffff;        // the lane sits out while cursor < my_skip
     // a vector instruction that reads a scalar register issues at half rate: keep the loop's constant in a vector one
     R floor2v = floor2;
     asm volatile("" : "+v"(floor2v));
@@ -268,20 +272,22 @@ static int launch_walk(nbe_engine* e, const void* src, uint64_t t0, uint64_t t1,
     A4* pos_out = (A4*)e->posm[dst_buf];
     A4* vel_out = (A4*)e->vel[dst_buf];
     float4* mirror_out = mixed ? e->mirror[dst_buf] : nullptr;
+    const uint32_t* tail_orig = (e->cfg.reference_quirks & NBE_QUIRK_DROP_TAIL) ? e->orig[e->orig_cur] : nullptr;
+    const unsigned tail_limit = (unsigned)(4 * (e->n / 4));
     dim3 grid(cdiv(nt, WALK_BLOCK));
     if (fused) {
         WALK_LAUNCH(OUT_FUSED, false) grid, dim3(WALK_BLOCK), 0, e->stream, (const NodeT*)e->tw.nodes,
                            e->tw.counters, (const R4*)src, (int)t0, (int)t1, (R)e->cfg.theta, floor2, G, dt, (A4*)e->acc,
-                           pos_in, vel_in, pos_out, vel_out, mirror_out, e->tw.d_interactions);
+                           pos_in, vel_in, pos_out, vel_out, mirror_out, e->tw.d_interactions, tail_orig, tail_limit);
     } else if (count) {
         NBE_HIP(hipMemsetAsync(e->tw.d_interactions, 0, 8 * sizeof(unsigned long long), e->stream));
         WALK_LAUNCH(OUT_ACC, true) grid, dim3(WALK_BLOCK), 0, e->stream, (const NodeT*)e->tw.nodes,
                            e->tw.counters, (const R4*)src, (int)t0, (int)t1, (R)e->cfg.theta, floor2, G, dt, (A4*)e->acc,
-                           pos_in, vel_in, pos_out, vel_out, mirror_out, e->tw.d_interactions);
+                           pos_in, vel_in, pos_out, vel_out, mirror_out, e->tw.d_interactions, tail_orig, tail_limit);
     } else {
         WALK_LAUNCH(OUT_ACC, false) grid, dim3(WALK_BLOCK), 0, e->stream, (const NodeT*)e->tw.nodes,
                            e->tw.counters, (const R4*)src, (int)t0, (int)t1, (R)e->cfg.theta, floor2, G, dt, (A4*)e->acc,
-                           pos_in, vel_in, pos_out, vel_out, mirror_out, e->tw.d_interactions);
+                           pos_in, vel_in, pos_out, vel_out, mirror_out, e->tw.d_interactions, tail_orig, tail_limit);
     }
     NBE_HIP(hipGetLastError());
     return NBE_OK;

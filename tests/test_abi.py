@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_struct_layouts_match_header_sizes():
-    assert C.sizeof(E.Config) == 2 * 4 + 4 * 8 + 3 * 8 + 8 + 2 * 4
+    assert C.sizeof(E.Config) == 2 * 4 + 4 * 8 + 3 * 8 + 8 + 3 * 4 + 4      # three ints, padded to 8
     assert C.sizeof(E.Stats) == 8 * 8 + 4 * 4
     assert C.sizeof(E.DeviceState) == 4 * 8 + 8 + 4 + 4
 
@@ -39,6 +39,7 @@ def test_default_config_holds_reference_constants():
     assert cfg.G == 6.67408e-11 and cfg.theta == 1.0 and cfg.dt == 3600.0 and cfg.eps == 0.0
     assert cfg.bound_width == 65536.0 and list(cfg.bound_center) == [0.0, 0.0, 0.0]
     assert cfg.mode == E.MODE_DIRECT and cfg.precision == E.PREC_F32 and cfg.collisions == 0
+    assert cfg.reference_quirks == 0
     assert lib.nbe_default_config(None) == -1
     assert b"NULL" in lib.nbe_last_error()
 
@@ -54,7 +55,12 @@ def test_create_rejects_bad_arguments():
     cfg.collisions = 2
     assert lib.nbe_create(C.byref(cfg), C.byref(h)) == -1 and not h.value
     cfg.collisions = 0
+    cfg.reference_quirks = E.QUIRK_REF_COM           # tree mode only
+    assert lib.nbe_create(C.byref(cfg), C.byref(h)) == -1 and not h.value
     cfg.mode = 1
+    cfg.reference_quirks = 4                         # unknown bit
+    assert lib.nbe_create(C.byref(cfg), C.byref(h)) == -1 and not h.value
+    cfg.reference_quirks = 0
     cfg.precision = 9
     assert lib.nbe_create(C.byref(cfg), C.byref(h)) == -1
     cfg.precision = 0
