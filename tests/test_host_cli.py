@@ -6,6 +6,8 @@ import subprocess
 import numpy as np
 import pytest
 
+from nbody_amd import physics
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BIN = os.path.join(ROOT, "host", "nbody")
 
@@ -117,3 +119,26 @@ def test_state_files_are_the_same_gob_stream_in_both_hosts(tmp_path):
     bad = tmp_path / "bad.data"; bad.write_bytes(open(name, "rb").read()[:-5])
     r = run(["-recode", str(bad)], tmp_path)
     assert r.returncode == 2 and b"gob" in r.stdout
+
+
+@pytest.mark.gpu
+def test_host_asgo_run_equals_the_reference_configuration_of_the_oracle(gpu, tmp_path):
+    """-asgo: the tree path with the Go program's own arithmetic (running cell centres tree.go:189-193, last n mod 4
+    bodies unwalked main.go:134-148).  A state file goes in (-state), 0.001 y = 8 frames = 9 iterations run
+    (main.go:80), and the final state this host saves as frame 9 is compared with 9 steps of the oracle as the
+    reference runs: fp64, 1e-10 of the largest coordinate."""
+    from nbody_amd import gobfile as G
+    from oracle import oracle as O
+    b = physics.makebodies(203, seed=4)                          # 205 bodies: body 204 is never walked
+    n = len(b.mass)
+    src = tmp_path / "in"; src.mkdir()
+    name = G.export_frame_data(0, np.arange(n, dtype=np.uint64), b.mass, np.full(n, 2.0), b.pos, b.vel, directory=str(src))
+    r = run(["-state", name, "-y", "0.001", "-tree", "-nocollision", "-asgo", "-precision", "f64", "-save"], tmp_path)
+    assert r.returncode == 0, r.stdout.decode()
+    f, ids, m2, r2, p2, v2 = G.import_frame_data(str(tmp_path / f"{9:010d}.data"))
+    rp, rv, ralive, _ = O.step(b.mass, b.pos, b.vel, nsteps=9, mode="tree", com_mode="ref", theta=1.0, drop_tail=True)
+    k = ids.astype(np.int64)
+    assert f == 9 and np.array_equal(k, np.nonzero(ralive)[0])
+    assert np.abs(p2 - rp[k]).max() <= 1e-10 * np.abs(rp[k]).max()
+    assert np.abs(v2 - rv[k]).max() <= 1e-10 * np.abs(rv[k]).max()
+    assert np.allclose(p2[k == n - 1][0], b.pos[n - 1] + 9 * 3600.0 * b.vel[n - 1], rtol=1e-14, atol=0)
