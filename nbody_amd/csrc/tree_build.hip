@@ -137,6 +137,31 @@ __global__ __launch_bounds__(256) void scan_single_kernel(const uint32_t* __rest
     }
 }
 
+// Radix sort offsets: the per-tile digit counts are stored digit-major, [digit][tile].  One workgroup per digit
+// turns its row into exclusive prefixes over the tiles and leaves the digit's total in totals[digit]; the scatter
+// kernel adds the digits below (a 256-entry scan it does itself).  One launch instead of the three of a scan
+// over the whole table.
+__global__ __launch_bounds__(256) void scan_rows_kernel(uint32_t* __restrict__ hist, int nblocks, uint32_t* __restrict__ totals)
+{
+    uint32_t* row = hist + (size_t)blockIdx.x * nblocks;
+    uint32_t carry = 0;
+    for (int base = 0; base < nblocks; base += SCAN_TILE) {
+        const int b = base + threadIdx.x * 8;
+        uint32_t v[8], s = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) { v[k] = b + k < nblocks ? row[b + k] : 0u; s += v[k]; }
+        uint32_t tot;
+        uint32_t off = carry + block_excl_scan(s, &tot);
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            if (b + k < nblocks) row[b + k] = off;
+            off += v[k];
+        }
+        carry += tot;
+    }
+    if (threadIdx.x == 0) totals[blockIdx.x] = carry;
+}
+
 #define SCAN_SINGLE_MAX (8 * SCAN_TILE)
 
 template <bool POPC>
@@ -193,14 +218,7 @@ __global__ __launch_bounds__(256) void keys_kernel(const R4* __restrict__ posm, 
         keys[i] = body_key((double)p.x, (double)p.y, (double)p.z, lox, loy, loz, width);
         idx[i] = (uint32_t)i;
     }
-    (void)counters;   // the number of live bodies falls out of the sort: see set_alive_count_kernel
-}
-
-// After the exclusive scan of the last radix pass (key bits 56..63), the offset of digit 255 in block 0 is the
-// number of keys below 0xff00...: every live key (63 bits) sorts below, the all-ones dead key at or above.
-__global__ void set_alive_count_kernel(const uint32_t* __restrict__ scanned_hist, int nblocks, int* __restrict__ counters)
-{
-    if (threadIdx.x == 0 && blockIdx.x == 0) counters[0] = (int)scanned_hist[(size_t)255 * nblocks];
+    (void)counters;   // the number of live bodies falls out of the sort's last pass (radix_scatter_kernel)
 }
 
 // ---- LSD radix sort, 8-bit digits, (key, index) pairs ---------------------------------------------------------
@@ -225,7 +243,9 @@ __global__ __launch_bounds__(256) void radix_hist_kernel(const uint64_t* __restr
 // carries the running count across rounds.  The tile is then reordered in LDS and written out in runs.
 __global__ __launch_bounds__(256) void radix_scatter_kernel(const uint64_t* __restrict__ kin, const uint32_t* __restrict__ vin,
                                                             uint64_t* __restrict__ kout, uint32_t* __restrict__ vout,
-                                                            const uint32_t* __restrict__ offsets, int n, int shift, int nblocks)
+                                                            const uint32_t* __restrict__ offsets,
+                                                            const uint32_t* __restrict__ totals, int n, int shift, int nblocks,
+                                                            int* __restrict__ alive_out)
 {
     __shared__ uint32_t wcount[4][256];
     __shared__ uint32_t wbase[4][256];
@@ -275,8 +295,13 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const uint64_t* __re
         uint32_t tot;
         const uint32_t dstart = block_excl_scan(dcount, &tot);     // contains the barriers that publish wbase
         dbase[tid] = dstart;
-        // where this digit's run goes in the output, minus its first slot in the tile: global = slot + gdelta
-        gdelta[tid] = offsets[(size_t)tid * nblocks + blockIdx.x] - dstart;
+        // keys with a smaller digit anywhere + keys with this digit in earlier tiles = where this digit's run goes
+        // in the output; minus its first slot in the tile: global = slot + gdelta
+        const uint32_t below = block_excl_scan(totals[tid], &tot);
+        gdelta[tid] = below + offsets[(size_t)tid * nblocks + blockIdx.x] - dstart;
+        // Last pass (key bits 56..63): every live key (63 bits) has a digit below 255, the all-ones key of a body
+        // outside the bound has 255, so the keys below digit 255 are the live bodies.
+        if (alive_out && blockIdx.x == 0 && tid == 255) *alive_out = (int)below;
     }
     __syncthreads();
     // Stage the tile in digit-sorted order in LDS, then write it out with consecutive threads on consecutive
@@ -863,6 +888,7 @@ int tree_workspace_reserve(nbe_engine* e)
     w.block_hist_len = 256 * nblocks;
     size_t scan_len = w.block_hist_len > cap + 1 ? w.block_hist_len : cap + 1;
     w.scan_tmp_len = cdiv(scan_len, SCAN_TILE) + 1;
+    if (w.scan_tmp_len < 256) w.scan_tmp_len = 256;      // also holds the 256 digit totals of a radix pass
     const size_t node_bytes = e->force64 ? sizeof(NodeD) : sizeof(NodeF);
     NBE_HIP(hipMalloc((void**)&w.keys[0], cap * 8));
     NBE_HIP(hipMalloc((void**)&w.keys[1], cap * 8));
@@ -924,10 +950,10 @@ static int sort_keys_t(nbe_engine* e)
         const int shift = pass * 8;
         hipLaunchKernelGGL(radix_hist_kernel, dim3(nblocks), dim3(256), 0, e->stream, w.keys[in], n, shift, nblocks,
                            w.block_hist);
-        NBE_TRY((device_exclusive_scan<false>(e, w.block_hist, w.block_hist, (size_t)256 * nblocks)));
-        if (pass == 7) hipLaunchKernelGGL(set_alive_count_kernel, dim3(1), dim3(64), 0, e->stream, w.block_hist, nblocks, w.counters);
+        hipLaunchKernelGGL(scan_rows_kernel, dim3(256), dim3(256), 0, e->stream, w.block_hist, nblocks, w.scan_tmp);
         hipLaunchKernelGGL(radix_scatter_kernel, dim3(nblocks), dim3(256), 0, e->stream, w.keys[in], w.sidx[in],
-                           w.keys[in ^ 1], w.sidx[in ^ 1], w.block_hist, n, shift, nblocks);
+                           w.keys[in ^ 1], w.sidx[in ^ 1], w.block_hist, w.scan_tmp, n, shift, nblocks,
+                           pass == 7 ? w.counters : (int*)nullptr);
         NBE_HIP(hipGetLastError());
         in ^= 1;
     }
