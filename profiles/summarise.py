@@ -17,7 +17,15 @@ base = os.path.join(root, "gpurun_out", f"prof_{tag}")
 
 
 def rows(pattern):
-    for path in glob.glob(os.path.join(base, pattern), recursive=True):
+    # gpurun merges every run's files into the same local directory: keep the newest run of each directory
+    # (rocprofv3 prefixes its files with the process id, so compare modification times, not names)
+    paths = glob.glob(os.path.join(base, pattern), recursive=True)
+    newest = {}
+    for path in paths:
+        d = os.path.dirname(path)
+        if d not in newest or os.path.getmtime(path) > os.path.getmtime(newest[d]):
+            newest[d] = path
+    for path in newest.values():
         with open(path, newline="") as f:
             for r in csv.DictReader(f):
                 yield r
@@ -29,7 +37,7 @@ def short(name):
               "scan_reduce_kernel", "scan_sums_kernel", "scan_apply_kernel", "keys_kernel", "permute_kernel",
               "radix_tree_kernel", "mark_cells_kernel", "emit_nodes_kernel", "cell_mass_kernel", "carry_dead_kernel",
               "refresh_mirror_kernel", "kinetic_kernel", "potential_kernel", "psum_apply_kernel", "psum_reduce_kernel",
-              "psum_scan_sums_kernel", "set_alive_count_kernel"):
+              "psum_scan_sums_kernel", "scan_rows_kernel", "scan_single_kernel", "ref_com_kernel"):
         if k in name:
             return k
     return name[:60]
