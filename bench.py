@@ -170,7 +170,7 @@ def main():
         workload = f"bh_theta0.5_fp32_plummer_{n >> 20}M" if n % (1 << 20) == 0 else f"bh_theta0.5_fp32_plummer_{n}"
     value = inter_per_step * args.steps / sec
     achieved = kernel_inter * FLOP_PER_INTERACTION / (kernel_ms * 1e-3) / 1e12
-    roofline = {"bound": "valu", "kernel": "direct_kernel<float,float,4>" if headline_mode == "direct" else "walk_kernel<float>",
+    roofline = {"bound": "valu", "kernel": "direct_kernel_f32<float,4,64,FUSED,EQM> (equal masses: the mass is folded into G)" if headline_mode == "direct" else "walk_kernel<float>",
                 "achieved": achieved, "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_VALU_PEAK_TFLOPS,
                 "traffic": traffic_from_profiles(workload), "kernel_ms": kernel_ms,
                 "flop_per_interaction": FLOP_PER_INTERACTION}
@@ -234,6 +234,16 @@ def main():
                                             "force_kernel_ms": kms4,
                                             "force_kernel_frac_of_fp32_valu_peak": 65536 * 65535 * FLOP_PER_INTERACTION / (kms4 * 1e-3) / 1e12 / FP32_VALU_PEAK_TFLOPS}
         e4.close()
+        # the headline cloud has equal masses, for which the pair loop leaves the mass out; the same cloud with masses
+        # varied by 0.1 % takes the general pair loop (one more packed multiply per pair of interactions)
+        pg = physics.plummer(1 << 20, seed=1)
+        e8 = Engine(mode="direct", precision="f32", device=local)
+        e8.upload(pg.pos, pg.vel, pg.mass * (1.0 + 1e-3 * np.sin(np.arange(1 << 20))))
+        kms8 = e8.time_force_kernel(3)
+        extra["direct_fp32_plummer_1M_unequal_masses"] = {
+            "force_kernel_ms": kms8, "interactions_per_s": (1 << 20) * ((1 << 20) - 1) / (kms8 * 1e-3),
+            "force_kernel_frac_of_fp32_valu_peak": (1 << 20) * ((1 << 20) - 1) * FLOP_PER_INTERACTION / (kms8 * 1e-3) / 1e12 / FP32_VALU_PEAK_TFLOPS}
+        e8.close()
         # benchmark configuration 1: the reference's default scene (main.go:32-37: 1000 bodies + 2 cores), tree, theta = 1
         g = physics.makebodies(1000, seed=1)
         e5 = Engine(mode="tree", precision="f32", theta=1.0, device=local)

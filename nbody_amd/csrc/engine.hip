@@ -170,6 +170,15 @@ static int upload_state(nbe_engine* e, size_t n, const double* pos, const double
     memset(&e->stats, 0, sizeof(e->stats));
     e->stats.n = n; e->stats.n_alive = n;
     e->host_nalive = n;
+    // Equal masses let the fp32 direct sum leave the mass out of its pair loop (direct.hip).  The value the kernels
+    // hold is the rounded one in fp32 state; masses change only through collisions, which keep the general kernel.
+    e->equal_mass = 0.0;
+    if (n > 0 && e->cfg.mode == NBE_MODE_DIRECT && !e->cfg.collisions && mass[0] > 0.0 && getenv("NBODY_NO_EQUAL_MASS") == nullptr) {
+        bool same = true;
+        for (size_t i = 1; i < n && same; i++) same = mass[i] == mass[0];
+        const double held = e->cfg.precision == NBE_PREC_F64 ? mass[0] : (double)(float)mass[0];
+        if (same && held > 0.0 && std::isfinite(held)) e->equal_mass = held;
+    }
     const size_t cap = n > 0 ? n : 1;
     for (int b = 0; b < 2; b++) {
         NBE_HIP(hipMalloc(&e->posm[b], cap * e->elem));

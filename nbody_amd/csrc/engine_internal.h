@@ -139,6 +139,7 @@ struct FrameStream {
 struct nbe_engine {
     nbe_config cfg{};
     size_t n = 0;
+    double equal_mass = 0.0;        // direct sum without collisions: the common mass if every body has the same, else 0
     bool state64 = false;           // fp64 state (MIXED and F64)
     bool force64 = false;           // fp64 pair arithmetic (F64)
     size_t elem = 16;               // bytes per 4-real element of the state

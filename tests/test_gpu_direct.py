@@ -152,3 +152,42 @@ def test_1m_bodies_newton_third_law_and_shard_consistency(gpu):
     pos, mass = f32(b.pos), f32(b.mass)
     t0, t1 = 500000, 500128
     check(acc[t0:t1], oracle_acc(mass, pos, t0=t0, t1=t1), "f32")
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 255, 256, 257, 1023, 4097, 70001])
+@pytest.mark.parametrize("precision", ["f32", "mixed"])
+def test_equal_mass_scenes_take_the_massless_pair_loop(gpu, n, precision, monkeypatch):
+    """When every body has the same mass the fp32 pair loop leaves the mass out (w = rinv^3, the mass folded into
+    G) and pads its last tile with sources 1e18 m away instead of massless ones.  Same tolerances as the general
+    kernel against the oracle, and the two kernels agree with each other to fp32 rounding of the sums; sizes cover
+    partial tiles and the split source ranges of small scenes.  A mass that is not representable in fp32 is
+    compared as the fp32 value the kernels hold."""
+    rng = np.random.default_rng(n)
+    pos = f32(rng.uniform(-1e4, 1e4, (n, 3))); vel = np.zeros((n, 3))
+    mass = np.full(n, 1e9 / 1048576 * 1.000001)
+    acc = engine_acc(pos, vel, mass, precision)
+    if n == 1:
+        assert np.all(acc == 0)
+        return
+    ref = oracle_acc(f32(mass), pos)
+    check(acc, ref, precision)
+    monkeypatch.setenv("NBODY_NO_EQUAL_MASS", "1")          # read at upload: the general kernel on the same scene
+    general = engine_acc(pos, vel, mass, precision)
+    monkeypatch.delenv("NBODY_NO_EQUAL_MASS")
+    er = relerr(acc, general)
+    assert np.median(er) <= 5e-7 and np.quantile(er, 0.999) <= 1e-4, (np.median(er), er.max())
+
+
+def test_equal_mass_steps_match_general_kernel_steps(gpu, monkeypatch):
+    """Ten fused steps of an equal-mass cloud with either pair loop: positions agree to fp32 rounding."""
+    b = physics.plummer(5000, seed=3)
+    out = []
+    for general in (False, True):
+        if general:
+            monkeypatch.setenv("NBODY_NO_EQUAL_MASS", "1")
+        with Engine(mode="direct", precision="mixed", eps=1.0) as e:
+            e.upload(b.pos, b.vel, b.mass)
+            e.step(10)
+            out.append(e.download()[0])
+    monkeypatch.delenv("NBODY_NO_EQUAL_MASS")
+    assert np.abs(out[0] - out[1]).max() <= 1e-6 * np.abs(out[1]).max()
