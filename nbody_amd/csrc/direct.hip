@@ -17,6 +17,9 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 
 #define DIRECT_TILE 256   // sources per LDS tile
+#ifndef DIRECT_ITILE
+#define DIRECT_ITILE 4    // targets per lane of the fp32 kernels
+#endif
 
 // Per-lane target state and the tile loop of the generic (scalar arithmetic) kernel; fp64 uses it.
 template <typename R, int ITILE> struct Targets;
@@ -323,8 +326,8 @@ int direct_forces(nbe_engine* e, int src_buf, uint64_t t0, uint64_t t1, bool fus
 {
     e->stats.interactions = (uint64_t)(t1 - t0) * (uint64_t)(e->n ? e->n - 1 : 0);
     switch (e->cfg.precision) {
-    case NBE_PREC_F32: return launch_direct<float, float, 4, 64>(e, e->posm[src_buf], t0, t1, fused, src_buf, dst_buf);
-    case NBE_PREC_MIXED: return launch_direct<float, double, 4, 64>(e, e->mirror[src_buf], t0, t1, fused, src_buf, dst_buf);
+    case NBE_PREC_F32: return launch_direct<float, float, DIRECT_ITILE, 64>(e, e->posm[src_buf], t0, t1, fused, src_buf, dst_buf);
+    case NBE_PREC_MIXED: return launch_direct<float, double, DIRECT_ITILE, 64>(e, e->mirror[src_buf], t0, t1, fused, src_buf, dst_buf);
     case NBE_PREC_F64: return launch_direct<double, double, 2, 256>(e, e->posm[src_buf], t0, t1, fused, src_buf, dst_buf);
     }
     nbe_set_error("unknown precision %d", e->cfg.precision);

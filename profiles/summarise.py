@@ -44,6 +44,7 @@ def short(name):
 
 
 # ---- kernel traces ----
+durations = {}
 with open(os.path.join(root, "profiles", f"{tag}_kernel_stats.txt"), "w") as f:
     for sub, cmd in (("trace_direct", "python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extra"),
                      ("trace_tree", "python3 bench.py --workload tree --steps 20 --warmup 2 --no-cpu-baseline --no-extra")):
@@ -53,6 +54,7 @@ with open(os.path.join(root, "profiles", f"{tag}_kernel_stats.txt"), "w") as f:
             a = agg[short(r["Kernel_Name"])]
             a[0] += 1; a[1] += d; a[2] = min(a[2], d); a[3] = max(a[3], d)
         total = sum(a[1] for a in agg.values()) or 1.0
+        durations[sub] = {k: a[1] / a[0] for k, a in agg.items() if a[0]}
         f.write(f"# rocprofv3 --kernel-trace --stats -- {cmd}   (tag {tag})\n")
         f.write(f"{'kernel':28s} {'calls':>7s} {'total_us':>14s} {'avg_us':>12s} {'min_us':>12s} {'max_us':>12s} {'share':>7s}\n")
         for k, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
@@ -61,7 +63,8 @@ with open(os.path.join(root, "profiles", f"{tag}_kernel_stats.txt"), "w") as f:
 
 # ---- counters ----
 pmc = defaultdict(lambda: defaultdict(lambda: [0, 0.0]))
-for sub in ("pmc_fetch_direct", "pmc_write_direct", "pmc_fetch_tree", "pmc_write_tree", "pmc_sq_direct", "pmc_sq_tree"):
+for sub in ("pmc_fetch_direct", "pmc_write_direct", "pmc_fetch_tree", "pmc_write_tree", "pmc_sq_direct", "pmc_sq_tree",
+            "pmc_lds_tree"):
     for r in rows(f"{sub}/**/*counter_collection.csv"):
         a = pmc[sub][(short(r["Kernel_Name"]), r["Counter_Name"])]
         a[0] += 1; a[1] += float(r["Counter_Value"])
@@ -89,5 +92,19 @@ for workload, kernel, fs, ws in (("direct_fp32_plummer_1M", "direct_kernel", "pm
 if traffic:
     with open(os.path.join(root, "profiles", "traffic.json"), "w") as f:
         json.dump(traffic, f, indent=1)
+# ---- HBM rate of every kernel of the Barnes-Hut step (sort and build phases are the HBM-bound ones) ----
+with open(os.path.join(root, "profiles", f"{tag}_hbm_phases.txt"), "w") as f:
+    f.write(f"# Barnes-Hut step, 1M-body Plummer sphere: HBM bytes per launch from the FETCH_SIZE / WRITE_SIZE passes,\n"
+            f"# (2*FETCH_SIZE + WRITE_SIZE) KiB, over the average duration of the kernel-trace pass (tag {tag}).\n"
+            f"# Peak 8000 GB/s.  Kernels of a few microseconds are launch-latency bound at this size.  The factor 2 on\n"
+            f"# FETCH_SIZE holds for wide coalesced reads; for 16-byte gathers (permute_kernel) it overstates the bytes.\n")
+    f.write(f"{'kernel':28s} {'avg_us':>9s} {'fetch_KiB':>11s} {'write_KiB':>11s} {'GB/s':>9s} {'of_peak':>8s}\n")
+    for k, us in sorted(durations.get("trace_tree", {}).items(), key=lambda kv: -kv[1]):
+        fe, wr = mean("pmc_fetch_tree", k, "FETCH_SIZE"), mean("pmc_write_tree", k, "WRITE_SIZE")
+        if fe is None or wr is None:
+            continue
+        gbs = (2 * fe + wr) * 1024 / (us * 1e-6) / 1e9
+        f.write(f"{k:28s} {us:9.2f} {fe:11.1f} {wr:11.1f} {gbs:9.1f} {gbs / 8000:8.3f}\n")
 print(open(os.path.join(root, "profiles", f"{tag}_kernel_stats.txt")).read())
+print(open(os.path.join(root, "profiles", f"{tag}_hbm_phases.txt")).read())
 print(json.dumps(traffic, indent=1))
