@@ -78,7 +78,7 @@ def test_ten_steps_equal_the_reference_configuration_of_the_golden_vectors(gpu, 
 
 
 def test_default_scene_100_steps_like_the_go_program(gpu):
-    """BASELINE configuration 1: main.go's default cloud (2 cores in front + 1000 bodies = 1002, so bodies 1000 and 1001
+    """The reference at its own scale: main.go's default cloud (2 cores in front + 1000 bodies = 1002, so bodies 1000 and 1001
     are never walked), theta 1, 100 steps, against the oracle run exactly as the reference runs."""
     b = physics.makebodies(1000, seed=7)
     mass, pos, vel = b.mass, b.pos, b.vel
