@@ -764,29 +764,72 @@ __device__ __forceinline__ double lane_value(double v, int src)
 // Applies the recurrence to the bodies held by the lanes of `mask`, in ascending lane order.  Only the additions
 // are serial (running mass, then running centre); the division and the products of all lanes run side by side in
 // between, which leaves every intermediate value exactly as the one-body-at-a-time loop rounds it.
+// The bodies are first packed into lanes 0 .. cnt-1 (one crossbar move), so that the serial loops can be unrolled
+// with constant lane numbers: a step is then two v_readlane, one v_add_f64 and a two-instruction latch instead
+// of a bit scan, a mask update, a compare and a branch (one wave runs this alone: instruction issue is its time).
+template <int K>
+__device__ __forceinline__ double lane_const(double v)
+{
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)bits, K);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(bits >> 32), K);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+template <int K, int END> struct RefSerial {
+    // running mass: after the call lane k (first <= k < cnt) holds m_first' + ... + m_k in `total`
+    static __device__ __forceinline__ void mass(double& M, double pm, double& total, int first, int cnt, int lane)
+    {
+#pragma clang fp contract(off)
+        if (K >= cnt) return;
+        if (K >= first) {
+            M = M + lane_const<K>(pm);
+            if (lane == K) total = M;
+        }
+        RefSerial<K + 1, END>::mass(M, pm, total, first, cnt, lane);
+    }
+    static __device__ __forceinline__ void centre(double& x, double& y, double& z, double tx, double ty, double tz, int first, int cnt)
+    {
+#pragma clang fp contract(off)
+        if (K >= cnt) return;
+        if (K >= first) { x = x + lane_const<K>(tx); y = y + lane_const<K>(ty); z = z + lane_const<K>(tz); }
+        RefSerial<K + 1, END>::centre(x, y, z, tx, ty, tz, first, cnt);
+    }
+};
+template <int END> struct RefSerial<END, END> {
+    static __device__ __forceinline__ void mass(double&, double, double&, int, int, int) {}
+    static __device__ __forceinline__ void centre(double&, double&, double&, double, double, double, int, int) {}
+};
+
 __device__ __forceinline__ void ref_com_push_lanes(RefCom& c, unsigned long long mask, double pm, double px, double py, double pz)
 {
 #pragma clang fp contract(off)
     const int lane = threadIdx.x & 63;
     if (mask == 0) return;
+    const int cnt = __popcll(mask);
+    if (mask != (cnt == 64 ? ~0ull : (1ull << cnt) - 1ull)) {
+        // lane r fetches the r-th hit (ascending lane order is kept)
+        const int rank = __popcll(mask & ((1ull << lane) - 1ull));
+        const bool hit = (mask >> lane) & 1ull;
+        int from = 0;                                   // pull: the lane number of the r-th set bit
+        {
+            // every hit lane announces itself to lane `rank` through the crossbar (push), then all pull
+            const int dst = hit ? rank : 63;            // non-hits aim at a lane nobody reads when cnt < 64
+            from = __builtin_amdgcn_ds_permute(dst << 2, hit ? lane : 0);
+        }
+        pm = __shfl(pm, from, 64); px = __shfl(px, from, 64); py = __shfl(py, from, 64); pz = __shfl(pz, from, 64);
+    }
+    int first = 0;
     if (!c.any) {                                    // tree.go:156-160: the first body's position and mass
-        const int src = __ffsll(mask) - 1;
-        mask &= mask - 1;
         c.any = true;
-        c.M = lane_value(pm, src); c.x = lane_value(px, src); c.y = lane_value(py, src); c.z = lane_value(pz, src);
+        c.M = lane_const<0>(pm); c.x = lane_const<0>(px); c.y = lane_const<0>(py); c.z = lane_const<0>(pz);
+        first = 1;
     }
     double my_total = 1.0;
-    for (unsigned long long m = mask; m; m &= m - 1) {            // tree.go:191
-        const int src = __ffsll(m) - 1;
-        c.M = c.M + lane_value(pm, src);
-        if (lane == src) my_total = c.M;
-    }
-    const double s = pm / my_total;                               // tree.go:192, b.Mass / n.totalMass
+    RefSerial<0, 64>::mass(c.M, pm, my_total, first, cnt, lane);              // tree.go:191
+    const double s = pm / my_total;                                           // tree.go:192, b.Mass / n.totalMass
     const double tx = px * s, ty = py * s, tz = pz * s;
-    for (unsigned long long m = mask; m; m &= m - 1) {
-        const int src = __ffsll(m) - 1;
-        c.x = c.x + lane_value(tx, src); c.y = c.y + lane_value(ty, src); c.z = c.z + lane_value(tz, src);
-    }
+    RefSerial<0, 64>::centre(c.x, c.y, c.z, tx, ty, tz, first, cnt);
 }
 
 // inv[upload index] = sorted index of a live body; 0xffffffff for bodies outside the bound.
@@ -848,8 +891,10 @@ __global__ __launch_bounds__(256) void ref_com_kernel(int n, const int* __restri
 #pragma unroll
             for (int k = 0; k < REF_UNROLL; k++) {
                 hit[k] = s[k] >= (uint32_t)a && s[k] <= (uint32_t)b;
-                pm[k] = 0; px[k] = 0; py[k] = 0; pz[k] = 0;
-                if (hit[k]) { const R4 p = posm[s[k]]; pm[k] = (double)p.w; px[k] = (double)p.x; py[k] = (double)p.y; pz[k] = (double)p.z; }
+                // unconditional (lanes without a hit read the cell's first body and ignore it): a load under a
+                // branch is waited for inside the branch, and the eight would run one after the other
+                const R4 p = posm[hit[k] ? s[k] : (uint32_t)a];
+                pm[k] = (double)p.w; px[k] = (double)p.x; py[k] = (double)p.y; pz[k] = (double)p.z;
             }
 #pragma unroll
             for (int k = 0; k < REF_UNROLL; k++)
