@@ -128,7 +128,14 @@ __device__ __forceinline__ bool node_opens(const RawD& nd, double r2, double the
 // needs the mass copied to a vector register) gives 1.84 ms.  Testing for the end once per two visits lets the
 // compiler interleave the two and wait too early (1.87 ms); taking the vote from the plain compare and masking
 // sleeping lanes with scalar logic instead of the select makes it rebuild the masks through vector registers.
-template <typename R, typename A, typename NodeT, int OUT, bool COUNT, bool SOFT>
+// GROUP (NBE_WALK_PER_WAVE): the opening test is taken per wave instead of per body: a cell is opened for all 64
+// bodies as soon as one of them would open it, and accepted only when all of them accept it.  Every body then
+// opens at least the cells its own walk would open (never a coarser interaction than the reference's criterion
+// allows, usually a finer one), nobody ever sits out, and the select / compare / copy instructions that keep the
+// per-body bookkeeping disappear from the visit; visits that open a cell skip the force arithmetic altogether.
+// The visit sequence of a wave is the same in both modes; the interaction set is not, so this is not the
+// reference's result and is off by default.
+template <typename R, typename A, typename NodeT, int OUT, bool COUNT, bool SOFT, bool GROUP>
 __global__ __launch_bounds__(WALK_BLOCK) void walk_kernel(
     const NodeT* __restrict__ nodes, const int* __restrict__ counters, const typename V4<R>::type* __restrict__ posm,
     int t0, int t1, R theta, R floor2, A G, A dt, typename V4<A>::type* __restrict__ acc_out,
@@ -168,6 +175,9 @@ __global__ __launch_bounds__(WALK_BLOCK) void walk_kernel(
     // last n mod 4 bodies of main.go:134-148; they sit out the whole traversal and are integrated with zero force
     const bool walked = valid && !(tail_orig && tail_orig[i] >= tail_limit);
     int my_skip = walked ? 0 : 0x7fffffff;        // the lane sits out while cursor < my_skip
+    // per-wave criterion: a lane without a body to walk stands infinitely far away, so it never asks to open a
+    // cell; what it accumulates is discarded below
+    if (GROUP && !walked) px = (R)INFINITY;
     // a vector instruction that reads a scalar register issues at half rate: keep the loop's constant in a vector one
     R floor2v = floor2;
     asm volatile("" : "+v"(floor2v));
@@ -188,11 +198,33 @@ __global__ __launch_bounds__(WALK_BLOCK) void walk_kernel(
         // The floor under r^2 (1e-12 m^2 unless softening is on) keeps rsq finite for the body's own leaf
         // and for bodies at distance 0, which then contribute exactly 0 because dx = dy = dz = 0.
         R r2 = fma(dx, dx, fma(dy, dy, fma(dz, dz, floor2v)));
+        int next;
+        if (GROUP) {
+            const bool open = node_opens(nd, SOFT ? r2 - floor2v : r2, theta);
+            const bool any_open = __builtin_amdgcn_ballot_w64(open) != 0;
+            next = any_open ? cur + 1 : skip;
+            there = request_raw(nodes, next, r2);
+            if (!any_open) {                           // wave-uniform: everybody takes the node
+                const R mass = as_real(nd.m);
+                const R rinv = rsq_dev(r2);
+                R rinv2 = rinv * rinv;
+                if (__is_same(R, float)) asm volatile("" : "+v"(rinv2));
+                const R w = rinv2 * (rinv * mass);
+                fx = fma(dx, w, fx);
+                fy = fma(dy, w, fy);
+                fz = fma(dz, w, fz);
+                if (COUNT) {
+                    const bool use = walked && (dx != (R)0 || dy != (R)0 || dz != (R)0);
+                    count += (unsigned)__popcll(__builtin_amdgcn_ballot_w64(use));
+                    if (use) phi += (A)(rinv * mass);
+                }
+            }
+        } else {
         const bool active = cur >= my_skip;
         // lanes sitting out get an infinite distance, so one compare is both the opening test and the vote
         const R rtest = active ? (SOFT ? r2 - floor2v : r2) : (R)INFINITY;
         const bool open = node_opens(nd, rtest, theta);
-        const int next = __builtin_amdgcn_ballot_w64(open) != 0 ? cur + 1 : skip;
+        next = __builtin_amdgcn_ballot_w64(open) != 0 ? cur + 1 : skip;
         there = request_raw(nodes, next, r2);      // the force arithmetic below runs while this is in flight
         const R mass = as_real(nd.m);
         const bool take = active && !open;
@@ -210,6 +242,7 @@ __global__ __launch_bounds__(WALK_BLOCK) void walk_kernel(
             const bool use = take && (dx != (R)0 || dy != (R)0 || dz != (R)0);
             count += (unsigned)__popcll(__builtin_amdgcn_ballot_w64(use));
             if (use) phi += (A)(rinv * mass);
+        }
         }
         ++it;
         if (BLOCKED && (it & 63) == 0) {
@@ -242,7 +275,9 @@ __global__ __launch_bounds__(WALK_BLOCK) void walk_kernel(
 #endif
     }
     if (!valid) return;
-    const A sx = ax + (A)fx, sy = ay + (A)fy, sz = az + (A)fz;
+    // (per-wave criterion: a body that is not walked stood at infinity and accumulated NaN)
+    const bool blank = GROUP && !walked;
+    const A sx = blank ? (A)0 : ax + (A)fx, sy = blank ? (A)0 : ay + (A)fy, sz = blank ? (A)0 : az + (A)fz;
     if (OUT == OUT_ACC) {
         A4 o; o.x = G * sx; o.y = G * sy; o.z = G * sz; o.w = phi;
         acc_out[i] = o;
@@ -252,7 +287,8 @@ __global__ __launch_bounds__(WALK_BLOCK) void walk_kernel(
 }
 
 #define WALK_LAUNCH(...)                                                                                     \
-    hipLaunchKernelGGL((soft ? walk_kernel<R, A, NodeT, __VA_ARGS__, true> : walk_kernel<R, A, NodeT, __VA_ARGS__, false>),
+    hipLaunchKernelGGL((group ? (soft ? walk_kernel<R, A, NodeT, __VA_ARGS__, true, true> : walk_kernel<R, A, NodeT, __VA_ARGS__, false, true>) \
+                              : (soft ? walk_kernel<R, A, NodeT, __VA_ARGS__, true, false> : walk_kernel<R, A, NodeT, __VA_ARGS__, false, false>)),
 
 template <typename R, typename A, typename NodeT>
 static int launch_walk(nbe_engine* e, const void* src, uint64_t t0, uint64_t t1, bool fused, bool count, int src_buf, int dst_buf)
@@ -265,6 +301,7 @@ static int launch_walk(nbe_engine* e, const void* src, uint64_t t0, uint64_t t1,
     const double tiny = __is_same(R, float) ? 1e-12 : 1e-60;
     const R floor2 = (R)(eps * eps > tiny ? eps * eps : tiny);
     const bool soft = eps * eps > tiny;
+    const bool group = e->cfg.walk_criterion == NBE_WALK_PER_WAVE;
     const A G = (A)e->cfg.G, dt = (A)e->cfg.dt;
     const bool mixed = e->cfg.precision == NBE_PREC_MIXED;
     const A4* pos_in = (const A4*)e->posm[src_buf];

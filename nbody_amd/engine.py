@@ -27,13 +27,14 @@ FRAME_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_size_t, C.POINTER(C.c_floa
 
 
 QUIRK_REF_COM, QUIRK_DROP_TAIL = 1, 2
+WALK_PER_BODY, WALK_PER_WAVE = 0, 1
 
 
 class Config(C.Structure):
     _fields_ = [("mode", C.c_int), ("precision", C.c_int), ("G", C.c_double), ("theta", C.c_double),
                 ("dt", C.c_double), ("eps", C.c_double), ("bound_center", C.c_double * 3),
                 ("bound_width", C.c_double), ("device", C.c_int), ("collisions", C.c_int),
-                ("reference_quirks", C.c_int)]
+                ("reference_quirks", C.c_int), ("walk_criterion", C.c_int)]
 
 
 class Stats(C.Structure):
@@ -116,7 +117,7 @@ class Engine:
 
     def __init__(self, mode="direct", precision="f32", theta=None, dt=None, eps=None, G=None,
                  bound_center=None, bound_width=None, device=0, collisions=False, ref_com=False,
-                 drop_tail=False):
+                 drop_tail=False, per_wave=False):
         self._lib = load_library()
         cfg = Config()
         self._check(self._lib.nbe_default_config(C.byref(cfg)))
@@ -139,6 +140,9 @@ class Engine:
         # the reference's running "centre of mass" (tree.go:189-193) and its unwalked last n mod 4 bodies
         # (main.go:134-148), for number-for-number comparisons with the Go program
         cfg.reference_quirks = (QUIRK_REF_COM if ref_com else 0) | (QUIRK_DROP_TAIL if drop_tail else 0)
+        # per_wave: the 64 bodies of a wavefront open cells together (faster, finer than the reference's per-body
+        # test, not its interaction set)
+        cfg.walk_criterion = WALK_PER_WAVE if per_wave else WALK_PER_BODY
         self.cfg = cfg
         self._h = C.c_void_p()
         self._check(self._lib.nbe_create(C.byref(cfg), C.byref(self._h)))

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_struct_layouts_match_header_sizes():
-    assert C.sizeof(E.Config) == 2 * 4 + 4 * 8 + 3 * 8 + 8 + 3 * 4 + 4      # three ints, padded to 8
+    assert C.sizeof(E.Config) == 2 * 4 + 4 * 8 + 3 * 8 + 8 + 4 * 4
     assert C.sizeof(E.Stats) == 8 * 8 + 4 * 4
     assert C.sizeof(E.DeviceState) == 4 * 8 + 8 + 4 + 4
 
