@@ -234,7 +234,7 @@ def main():
                                             "force_kernel_ms": kms4,
                                             "force_kernel_frac_of_fp32_valu_peak": 65536 * 65535 * FLOP_PER_INTERACTION / (kms4 * 1e-3) / 1e12 / FP32_VALU_PEAK_TFLOPS}
         e4.close()
-        # the 1M-body Barnes-Hut step with the opening test taken per wave of 64 bodies instead of per body: finer
+        # the 1M-body Barnes-Hut step with the opening test taken per wave of 128 bodies instead of per body: finer
         # interactions than the reference's criterion asks for, not its interaction set (off by default)
         pw = physics.plummer(1 << 20, seed=1)
         e9 = Engine(mode="tree", precision="f32", theta=0.5, device=local, per_wave=True)
@@ -245,7 +245,7 @@ def main():
         extra["bh_theta0.5_fp32_plummer_1M_per_wave_criterion"] = {
             "ms_per_step": 1e3 * s9 / 20, "ms_force": st9.ms_force, "interactions_per_step": int(st9.interactions),
             "interactions_per_s": st9.interactions * 20 / s9,
-            "note": "NBE_WALK_PER_WAVE: a cell is opened for all 64 bodies of a wavefront when one of them would open it"}
+            "note": "NBE_WALK_PER_WAVE: a cell is opened for all 128 bodies of a wavefront when one of them would open it"}
         e9.close()
         # the headline cloud has equal masses, for which the pair loop leaves the mass out; the same cloud with masses
         # varied by 0.1 % takes the general pair loop (one more packed multiply per pair of interactions)

@@ -57,11 +57,12 @@ typedef struct {
 /* Who decides whether a cell is opened (tree.go:216-217, edge / distance > theta).
  *   NBE_WALK_PER_BODY   every body for itself, as the reference's recursion does: each body receives exactly the
  *                       interactions of tree.go:202-240.
- *   NBE_WALK_PER_WAVE   the 64 Morton-consecutive bodies that share a wavefront decide together: a cell is opened for
- *                       all of them when one of them would open it.  No body ever gets a coarser interaction than
- *                       the reference's test allows, most get finer ones (about 1.7x the force evaluations at
- *                       theta = 0.5), and the walk is about 1.5x faster because the per-body bookkeeping is gone.
- *                       Not the reference's interaction set: for production runs, not for parity checks. */
+ *   NBE_WALK_PER_WAVE   the 128 Morton-consecutive bodies that share a wavefront (two per lane; the aligned 128-body
+ *                       chunks of the sorted order) decide together: a cell is opened for all of them when one of them
+ *                       would open it.  No body ever gets a coarser interaction than the reference's test allows, most
+ *                       get finer ones (about twice the force evaluations at theta = 0.5), and the walk is 1.3-1.4x
+ *                       faster because the per-body bookkeeping is gone and the arithmetic packs.  Not the reference's
+ *                       interaction set: for production runs, not for parity checks. */
 enum { NBE_WALK_PER_BODY = 0, NBE_WALK_PER_WAVE = 1 };
 
 /* Two things the reference's tree path does that a gravity solver would not, reproduced on request so that a run

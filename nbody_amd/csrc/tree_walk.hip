@@ -128,14 +128,7 @@ __device__ __forceinline__ bool node_opens(const RawD& nd, double r2, double the
 // needs the mass copied to a vector register) gives 1.84 ms.  Testing for the end once per two visits lets the
 // compiler interleave the two and wait too early (1.87 ms); taking the vote from the plain compare and masking
 // sleeping lanes with scalar logic instead of the select makes it rebuild the masks through vector registers.
-// GROUP (NBE_WALK_PER_WAVE): the opening test is taken per wave instead of per body: a cell is opened for all 64
-// bodies as soon as one of them would open it, and accepted only when all of them accept it.  Every body then
-// opens at least the cells its own walk would open (never a coarser interaction than the reference's criterion
-// allows, usually a finer one), nobody ever sits out, and the select / compare / copy instructions that keep the
-// per-body bookkeeping disappear from the visit; visits that open a cell skip the force arithmetic altogether.
-// The visit sequence of a wave is the same in both modes; the interaction set is not, so this is not the
-// reference's result and is off by default.
-template <typename R, typename A, typename NodeT, int OUT, bool COUNT, bool SOFT, bool GROUP>
+template <typename R, typename A, typename NodeT, int OUT, bool COUNT, bool SOFT>
 __global__ __launch_bounds__(WALK_BLOCK) void walk_kernel(
     const NodeT* __restrict__ nodes, const int* __restrict__ counters, const typename V4<R>::type* __restrict__ posm,
     int t0, int t1, R theta, R floor2, A G, A dt, typename V4<A>::type* __restrict__ acc_out,
@@ -175,9 +168,6 @@ __global__ __launch_bounds__(WALK_BLOCK) void walk_kernel(
     // last n mod 4 bodies of main.go:134-148; they sit out the whole traversal and are integrated with zero force
     const bool walked = valid && !(tail_orig && tail_orig[i] >= tail_limit);
     int my_skip = walked ? 0 : 0x7fffffff;        // the lane sits out while cursor < my_skip
-    // per-wave criterion: a lane without a body to walk stands infinitely far away, so it never asks to open a
-    // cell; what it accumulates is discarded below
-    if (GROUP && !walked) px = (R)INFINITY;
     // a vector instruction that reads a scalar register issues at half rate: keep the loop's constant in a vector one
     R floor2v = floor2;
     asm volatile("" : "+v"(floor2v));
@@ -198,33 +188,11 @@ __global__ __launch_bounds__(WALK_BLOCK) void walk_kernel(
         // The floor under r^2 (1e-12 m^2 unless softening is on) keeps rsq finite for the body's own leaf
         // and for bodies at distance 0, which then contribute exactly 0 because dx = dy = dz = 0.
         R r2 = fma(dx, dx, fma(dy, dy, fma(dz, dz, floor2v)));
-        int next;
-        if (GROUP) {
-            const bool open = node_opens(nd, SOFT ? r2 - floor2v : r2, theta);
-            const bool any_open = __builtin_amdgcn_ballot_w64(open) != 0;
-            next = any_open ? cur + 1 : skip;
-            there = request_raw(nodes, next, r2);
-            if (!any_open) {                           // wave-uniform: everybody takes the node
-                const R mass = as_real(nd.m);
-                const R rinv = rsq_dev(r2);
-                R rinv2 = rinv * rinv;
-                if (__is_same(R, float)) asm volatile("" : "+v"(rinv2));
-                const R w = rinv2 * (rinv * mass);
-                fx = fma(dx, w, fx);
-                fy = fma(dy, w, fy);
-                fz = fma(dz, w, fz);
-                if (COUNT) {
-                    const bool use = walked && (dx != (R)0 || dy != (R)0 || dz != (R)0);
-                    count += (unsigned)__popcll(__builtin_amdgcn_ballot_w64(use));
-                    if (use) phi += (A)(rinv * mass);
-                }
-            }
-        } else {
         const bool active = cur >= my_skip;
         // lanes sitting out get an infinite distance, so one compare is both the opening test and the vote
         const R rtest = active ? (SOFT ? r2 - floor2v : r2) : (R)INFINITY;
         const bool open = node_opens(nd, rtest, theta);
-        next = __builtin_amdgcn_ballot_w64(open) != 0 ? cur + 1 : skip;
+        const int next = __builtin_amdgcn_ballot_w64(open) != 0 ? cur + 1 : skip;
         there = request_raw(nodes, next, r2);      // the force arithmetic below runs while this is in flight
         const R mass = as_real(nd.m);
         const bool take = active && !open;
@@ -242,7 +210,6 @@ __global__ __launch_bounds__(WALK_BLOCK) void walk_kernel(
             const bool use = take && (dx != (R)0 || dy != (R)0 || dz != (R)0);
             count += (unsigned)__popcll(__builtin_amdgcn_ballot_w64(use));
             if (use) phi += (A)(rinv * mass);
-        }
         }
         ++it;
         if (BLOCKED && (it & 63) == 0) {
@@ -275,9 +242,7 @@ __global__ __launch_bounds__(WALK_BLOCK) void walk_kernel(
 #endif
     }
     if (!valid) return;
-    // (per-wave criterion: a body that is not walked stood at infinity and accumulated NaN)
-    const bool blank = GROUP && !walked;
-    const A sx = blank ? (A)0 : ax + (A)fx, sy = blank ? (A)0 : ay + (A)fy, sz = blank ? (A)0 : az + (A)fz;
+    const A sx = ax + (A)fx, sy = ay + (A)fy, sz = az + (A)fz;
     if (OUT == OUT_ACC) {
         A4 o; o.x = G * sx; o.y = G * sy; o.z = G * sz; o.w = phi;
         acc_out[i] = o;
@@ -286,9 +251,135 @@ __global__ __launch_bounds__(WALK_BLOCK) void walk_kernel(
     }
 }
 
+// ---- per-wave criterion, two bodies per lane ----------------------------------------------------------------
+// NBE_WALK_PER_WAVE.  The 128 Morton-consecutive bodies of a wavefront (lane l owns bodies base + l and
+// base + 64 + l) decide together: a cell is opened for all of them as soon as one of them would open it
+// (tree.go:216-217 evaluated for each, decided for all), and accepted only when all accept it.  Every body then
+// opens at least the cells its own walk would open, nobody ever sits out, and the selects, compares and the copy
+// that keep the per-body bookkeeping of walk_kernel are gone: a visit is 3 packed subtractions, 3 packed fma and two
+// compares, plus, when the node is accepted, 2 rsq, 3 packed products and 3 packed fma for the two bodies.  Two bodies
+// per lane halve the node records fetched per body and give every fetch twice the arithmetic to hide under.
+// Not the reference's interaction set (finer), so it is off by default.
+template <typename R, typename A, typename NodeT, int OUT, bool COUNT, bool SOFT>
+__global__ __launch_bounds__(WALK_BLOCK) void walk_group_kernel(
+    const NodeT* __restrict__ nodes, const int* __restrict__ counters, const typename V4<R>::type* __restrict__ posm,
+    int t0, int t1, R theta, R floor2, A G, A dt, typename V4<A>::type* __restrict__ acc_out,
+    const typename V4<A>::type* __restrict__ pos_in, const typename V4<A>::type* __restrict__ vel_in,
+    typename V4<A>::type* __restrict__ pos_out, typename V4<A>::type* __restrict__ vel_out,
+    float4* __restrict__ mirror_out, unsigned long long* __restrict__ interactions)
+{
+    using R4 = typename V4<R>::type;
+    using A4 = typename V4<A>::type;
+    typedef R R2 __attribute__((ext_vector_type(2)));
+    constexpr bool BLOCKED = !__is_same(R, A);
+    const int na = counters[0];
+    const int total = counters[1];
+    const int tend = t1 < na ? t1 : na;
+    // same XCD-aware placement as walk_kernel: the workgroups of one XCD own a contiguous eighth of the bodies
+    const unsigned nwg = gridDim.x, q8 = nwg / 8, r8 = nwg % 8, xcd = blockIdx.x % 8;
+    const unsigned wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + blockIdx.x / 8;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int idx[2];
+    // groups are the aligned 128-body chunks of the sorted order whatever range [t0, t1) this launch covers, so a
+    // sharded run forms the same groups as one engine
+    idx[0] = (t0 & ~127) + (int)wg * (2 * WALK_BLOCK) + wave * 128 + lane;
+    idx[1] = idx[0] + 64;
+    bool valid[2];
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const int i = idx[k];
+        if (OUT == OUT_FUSED && i >= t0 && i >= tend && i < t1) {     // bodies removed by the bound check move on unchanged
+            pos_out[i] = pos_in[i];
+            vel_out[i] = vel_in[i];
+            if (mirror_out) { const A4 p = pos_in[i]; mirror_out[i] = make_float4((float)p.x, (float)p.y, (float)p.z, (float)p.w); }
+        }
+        valid[k] = i >= t0 && i < tend;
+    }
+    if (__ballot(valid[0] || valid[1]) == 0 || total <= 0) return;
+
+    // a lane without a body stands infinitely far away: it never asks to open a cell, and what it sums is dropped
+    R2 px = {(R)INFINITY, (R)INFINITY}, py = {0, 0}, pz = {0, 0};
+    // every live body of the chunk takes part in the decisions, also one that belongs to another shard: the groups
+    // and their votes are then the same however the bodies are sharded; only the own bodies are written
+    if (idx[0] < na) { const R4 p = posm[idx[0]]; px.x = p.x; py.x = p.y; pz.x = p.z; }
+    if (idx[1] < na) { const R4 p = posm[idx[1]]; px.y = p.x; py.y = p.y; pz.y = p.z; }
+    R2 fx = {0, 0}, fy = {0, 0}, fz = {0, 0};
+    A ax[2] = {0, 0}, ay[2] = {0, 0}, az[2] = {0, 0}, phi[2] = {0, 0};
+    R2 floor2v = {floor2, floor2};
+    asm volatile("" : "+v"(floor2v));
+    // Everything the epilogue needs from the kernel arguments is fetched here, ahead of the loop: a scalar load that
+    // the compiler places at the loop's exit could be given the registers of the node request that is still in flight
+    // there (the build's check of the device assembly rejects exactly that).
+    asm volatile("" :: "s"(G), "s"(dt), "s"(acc_out), "s"(interactions));
+    unsigned count = 0;
+    int it = 0;
+    int cur = 0;
+    auto visit = [&](auto& here, auto& there) -> bool {
+        const auto nd = arrived(here);
+        const int skip = nd.skip;
+        const R nx = as_real(nd.x), ny = as_real(nd.y), nz = as_real(nd.z);
+        const R2 dx = R2{nx, nx} - px, dy = R2{ny, ny} - py, dz = R2{nz, nz} - pz;
+        R2 r2 = __builtin_elementwise_fma(dx, dx, __builtin_elementwise_fma(dy, dy, __builtin_elementwise_fma(dz, dz, floor2v)));
+        const R2 rt = SOFT ? r2 - floor2v : r2;
+        const bool open = node_opens(nd, rt.x, theta) || node_opens(nd, rt.y, theta);
+        const bool any_open = __builtin_amdgcn_ballot_w64(open) != 0;
+        const int next = any_open ? cur + 1 : skip;
+        R keep = r2.x;
+        there = request_raw(nodes, next, keep);
+        r2.x = keep;
+        if (!any_open) {                               // wave-uniform: all 128 bodies take the node
+            const R mass = as_real(nd.m);
+            const R2 rinv = {rsq_dev(r2.x), rsq_dev(r2.y)};
+            const R2 w = (rinv * rinv) * (rinv * R2{mass, mass});
+            fx = __builtin_elementwise_fma(dx, w, fx);
+            fy = __builtin_elementwise_fma(dy, w, fy);
+            fz = __builtin_elementwise_fma(dz, w, fz);
+            if (COUNT) {
+                const bool u0 = valid[0] && (dx.x != (R)0 || dy.x != (R)0 || dz.x != (R)0);
+                const bool u1 = valid[1] && (dx.y != (R)0 || dy.y != (R)0 || dz.y != (R)0);
+                count += (unsigned)__popcll(__builtin_amdgcn_ballot_w64(u0)) + (unsigned)__popcll(__builtin_amdgcn_ballot_w64(u1));
+                if (u0) phi[0] += (A)(rinv.x * mass);
+                if (u1) phi[1] += (A)(rinv.y * mass);
+            }
+        }
+        ++it;
+        if (BLOCKED && (it & 63) == 0) {
+            ax[0] += (A)fx.x; ay[0] += (A)fy.x; az[0] += (A)fz.x;
+            ax[1] += (A)fx.y; ay[1] += (A)fy.y; az[1] += (A)fz.y;
+            fx = R2{0, 0}; fy = R2{0, 0}; fz = R2{0, 0};
+        }
+        cur = next;
+        if (next < total) return true;
+        settle(there);       // the record requested last is never read, but has to land before its registers are reused
+        return false;
+    };
+    R none = 0;
+    auto slot_a = request_raw(nodes, 0, none);
+    decltype(slot_a) slot_b;
+    for (;;) {
+        if (!visit(slot_a, slot_b)) break;
+        if (!visit(slot_b, slot_a)) break;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+    if (COUNT && lane == 0 && interactions) atomicAdd(interactions, (unsigned long long)count);
+    const R fxs[2] = {fx.x, fx.y}, fys[2] = {fy.x, fy.y}, fzs[2] = {fz.x, fz.y};
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        if (!valid[k]) continue;
+        const int i = idx[k];
+        const A sx = ax[k] + (A)fxs[k], sy = ay[k] + (A)fys[k], sz = az[k] + (A)fzs[k];
+        if (OUT == OUT_ACC) {
+            A4 o; o.x = G * sx; o.y = G * sy; o.z = G * sz; o.w = phi[k];
+            acc_out[i] = o;
+        } else {
+            kick_drift<A>(i, G * sx, G * sy, G * sz, dt, pos_in, vel_in, pos_out, vel_out, mirror_out);
+        }
+    }
+}
+
 #define WALK_LAUNCH(...)                                                                                     \
-    hipLaunchKernelGGL((group ? (soft ? walk_kernel<R, A, NodeT, __VA_ARGS__, true, true> : walk_kernel<R, A, NodeT, __VA_ARGS__, false, true>) \
-                              : (soft ? walk_kernel<R, A, NodeT, __VA_ARGS__, true, false> : walk_kernel<R, A, NodeT, __VA_ARGS__, false, false>)),
+    hipLaunchKernelGGL((soft ? walk_kernel<R, A, NodeT, __VA_ARGS__, true> : walk_kernel<R, A, NodeT, __VA_ARGS__, false>),
 
 template <typename R, typename A, typename NodeT>
 static int launch_walk(nbe_engine* e, const void* src, uint64_t t0, uint64_t t1, bool fused, bool count, int src_buf, int dst_buf)
@@ -311,6 +402,25 @@ static int launch_walk(nbe_engine* e, const void* src, uint64_t t0, uint64_t t1,
     float4* mirror_out = mixed ? e->mirror[dst_buf] : nullptr;
     const uint32_t* tail_orig = (e->cfg.reference_quirks & NBE_QUIRK_DROP_TAIL) ? e->orig[e->orig_cur] : nullptr;
     const unsigned tail_limit = (unsigned)(4 * (e->n / 4));
+    if (group) {
+        dim3 ggrid(cdiv((size_t)(t1 - (t0 & ~127ull)), 2 * WALK_BLOCK));
+#define GROUP_LAUNCH(...)                                                                                    \
+    hipLaunchKernelGGL((soft ? walk_group_kernel<R, A, NodeT, __VA_ARGS__, true> : walk_group_kernel<R, A, NodeT, __VA_ARGS__, false>), \
+                       ggrid, dim3(WALK_BLOCK), 0, e->stream, (const NodeT*)e->tw.nodes, e->tw.counters, (const R4*)src,  \
+                       (int)t0, (int)t1, (R)e->cfg.theta, floor2, G, dt, (A4*)e->acc, pos_in, vel_in, pos_out, vel_out,   \
+                       mirror_out, e->tw.d_interactions)
+        if (fused) {
+            GROUP_LAUNCH(OUT_FUSED, false);
+        } else if (count) {
+            NBE_HIP(hipMemsetAsync(e->tw.d_interactions, 0, 8 * sizeof(unsigned long long), e->stream));
+            GROUP_LAUNCH(OUT_ACC, true);
+        } else {
+            GROUP_LAUNCH(OUT_ACC, false);
+        }
+#undef GROUP_LAUNCH
+        NBE_HIP(hipGetLastError());
+        return NBE_OK;
+    }
     dim3 grid(cdiv(nt, WALK_BLOCK));
     if (fused) {
         WALK_LAUNCH(OUT_FUSED, false) grid, dim3(WALK_BLOCK), 0, e->stream, (const NodeT*)e->tw.nodes,

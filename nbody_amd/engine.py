@@ -140,7 +140,7 @@ class Engine:
         # the reference's running "centre of mass" (tree.go:189-193) and its unwalked last n mod 4 bodies
         # (main.go:134-148), for number-for-number comparisons with the Go program
         cfg.reference_quirks = (QUIRK_REF_COM if ref_com else 0) | (QUIRK_DROP_TAIL if drop_tail else 0)
-        # per_wave: the 64 bodies of a wavefront open cells together (faster, finer than the reference's per-body
+        # per_wave: the 128 bodies of a wavefront open cells together (faster, finer than the reference's per-body
         # test, not its interaction set)
         cfg.walk_criterion = WALK_PER_WAVE if per_wave else WALK_PER_BODY
         self.cfg = cfg

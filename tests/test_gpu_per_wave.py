@@ -1,5 +1,5 @@
-"""The per-wave opening criterion (NBE_WALK_PER_WAVE): the 64 Morton-consecutive bodies of a wavefront open a cell
-together as soon as one of them would open it (tree.go:216-217 evaluated for each, decided for all).
+"""The per-wave opening criterion (NBE_WALK_PER_WAVE): the 128 Morton-consecutive bodies of a wavefront (two per
+lane) open a cell together as soon as one of them would open it (tree.go:216-217 evaluated for each, decided for all).
 
 It is not the reference's interaction set, so it is checked against (a) a replay of exactly that rule in numpy
 over the engine's own node table (fp64 engine: accelerations <= 1e-10, interaction counts equal), (b) the fp64
@@ -24,8 +24,8 @@ def replay_per_wave(nodes, theta):
     total = len(nodes)
     acc = np.zeros((len(leaves), 3))
     count = 0
-    for w0 in range(0, len(leaves), 64):
-        p = com[leaves[w0:w0 + 64]]
+    for w0 in range(0, len(leaves), 128):
+        p = com[leaves[w0:w0 + 128]]
         a = np.zeros_like(p)
         cur = 0
         while cur < total:
@@ -42,11 +42,11 @@ def replay_per_wave(nodes, theta):
             a += d * wgt[:, None]
             count += int(nz.sum())
             cur = skip[cur]
-        acc[w0:w0 + 64] = a
+        acc[w0:w0 + 128] = a
     return acc, count
 
 
-@pytest.mark.parametrize("n,theta", [(2, 0.5), (64, 0.5), (65, 1.0), (1000, 0.5), (4097, 0.7)])
+@pytest.mark.parametrize("n,theta", [(2, 0.5), (64, 0.5), (65, 1.0), (129, 0.5), (1000, 0.5), (4097, 0.7)])
 def test_fp64_engine_equals_a_replay_of_the_rule(gpu, n, theta):
     rng = np.random.default_rng(n)
     pos = rng.normal(0, 3e3, (n, 3)); mass = np.abs(rng.normal(1e3, 500, n)) + 1
@@ -98,3 +98,29 @@ def test_per_wave_needs_plain_tree_mode(gpu):
     for kw in (dict(mode="direct"), dict(mode="tree", collisions=True), dict(mode="tree", ref_com=True)):
         with pytest.raises(EngineError):
             Engine(per_wave=True, **kw)
+
+
+def test_shards_form_the_same_groups_as_one_engine(gpu):
+    """Groups are the aligned 128-body chunks of the sorted order, so uneven shards (boundaries inside a chunk)
+    advance their bodies to the same bits as an engine that advances all of them."""
+    import torch
+    from nbody_amd.sharded import EngineShard
+    b = physics.plummer(3000, seed=9)
+
+    def advanced(first, count):
+        with Engine(mode="tree", precision="f32", theta=0.5, per_wave=True) as e:
+            e.upload(b.pos, b.vel, b.mass)
+            sh = EngineShard(e)
+            sh.set_shard(first, count)
+            sh.prepare()
+            sh.advance()
+            pos, vel = sh.next_state()
+            torch.cuda.synchronize()
+            out = pos[first:first + count].cpu().numpy().copy(), vel[first:first + count].cpu().numpy().copy()
+            sh.commit()
+            return out
+
+    full_pos, full_vel = advanced(0, 3000)
+    for first, count in ((0, 1000), (1000, 1111), (2111, 889)):
+        p, v = advanced(first, count)
+        assert np.array_equal(p, full_pos[first:first + count]) and np.array_equal(v, full_vel[first:first + count])
