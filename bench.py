@@ -131,9 +131,9 @@ def main():
         if world > 1:
             dist.barrier()
 
-    def run(mode, n, precision, theta, steps, warmup, seed=1):
+    def run(mode, n, precision, theta, steps, warmup, seed=1, **engine_kw):
         b = physics.plummer(n, seed=seed)
-        eng = Engine(mode=mode, precision=precision, theta=theta, device=local)
+        eng = Engine(mode=mode, precision=precision, theta=theta, device=local, **engine_kw)
         eng.upload(b.pos, b.vel, b.mass)
         del b
         if world > 1 or force_dist:
@@ -221,6 +221,11 @@ def main():
                 "sort_algorithmic_GBps": m * 200.0 / (st3.ms_sort * 1e-3) / 1e9 if st3.ms_sort > 0 else None,
                 "build_algorithmic_GBps": m * 130.0 / (st3.ms_build * 1e-3) / 1e9 if st3.ms_build > 0 else None})
         e3.close()
+        # the same cloud with the opening test taken per wavefront of 128 bodies (finer than the reference's per-body
+        # test, not its interaction set; off by default), also on every GPU count
+        e3w, s3w = run("tree", m, "f32", 0.5, 5, 1, per_wave=True)
+        extra["bh_theta0.5_fp32_plummer_16M_per_wave_criterion"] = {"steps_per_s": 5 / s3w, "ms_per_step": 1e3 * s3w / 5}
+        e3w.close()
 
     if not args.no_extra and world == 1:
         # benchmark configuration 2: 65,536-body uniform cloud, fp32 direct sum

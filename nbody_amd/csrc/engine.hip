@@ -67,8 +67,8 @@ extern "C" int nbe_create(const nbe_config* cfg, nbe_engine** out)
     if (cfg->collisions != 0 && cfg->collisions != 1) { nbe_set_error("collisions must be 0 or 1"); return NBE_E_INVALID; }
     if (cfg->reference_quirks & ~(NBE_QUIRK_REF_COM | NBE_QUIRK_DROP_TAIL)) { nbe_set_error("unknown bit in reference_quirks"); return NBE_E_INVALID; }
     if (cfg->walk_criterion != NBE_WALK_PER_BODY && cfg->walk_criterion != NBE_WALK_PER_WAVE) { nbe_set_error("bad walk_criterion %d", cfg->walk_criterion); return NBE_E_INVALID; }
-    if (cfg->walk_criterion == NBE_WALK_PER_WAVE && (cfg->mode != NBE_MODE_TREE || cfg->reference_quirks || cfg->collisions)) {
-        nbe_set_error("the per-wave walk criterion needs tree mode without collisions and without reference_quirks");
+    if (cfg->walk_criterion == NBE_WALK_PER_WAVE && (cfg->mode != NBE_MODE_TREE || cfg->reference_quirks)) {
+        nbe_set_error("the per-wave walk criterion needs tree mode without reference_quirks");
         return NBE_E_INVALID;
     }
     if (cfg->reference_quirks && cfg->mode != NBE_MODE_TREE) { nbe_set_error("reference_quirks apply to tree mode only"); return NBE_E_INVALID; }

@@ -95,7 +95,7 @@ def test_steps_and_drift_with_the_per_wave_walk(gpu):
 
 def test_per_wave_needs_plain_tree_mode(gpu):
     from nbody_amd.engine import EngineError
-    for kw in (dict(mode="direct"), dict(mode="tree", collisions=True), dict(mode="tree", ref_com=True)):
+    for kw in (dict(mode="direct"), dict(mode="tree", ref_com=True), dict(mode="tree", drop_tail=True)):
         with pytest.raises(EngineError):
             Engine(per_wave=True, **kw)
 
@@ -124,3 +124,17 @@ def test_shards_form_the_same_groups_as_one_engine(gpu):
     for first, count in ((0, 1000), (1000, 1111), (2111, 889)):
         p, v = advanced(first, count)
         assert np.array_equal(p, full_pos[first:first + count]) and np.array_equal(v, full_vel[first:first + count])
+
+
+def test_collisions_run_behind_the_per_wave_walk(gpu):
+    """The collision search, queue and merge do not depend on who opened which cell for the forces: the first step
+    of a dense cloud queues and merges exactly what it does behind the per-body walk."""
+    b = physics.plummer(6000, seed=4, a=60.0)
+    merges = {}
+    for per_wave in (False, True):
+        with Engine(mode="tree", precision="f64", theta=0.5, collisions=True, per_wave=per_wave) as e:
+            e.upload(b.pos, b.vel, b.mass)
+            e.step(1)
+            st = e.stats()
+            merges[per_wave] = (st.merges, st.collision_pairs, st.n_alive)
+    assert merges[True] == merges[False] and merges[True][0] > 0
