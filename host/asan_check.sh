@@ -19,4 +19,5 @@ run -y 0.002
 run -n 400 -y 0.002 -seed 2
 run -n 300 -y 0.002 -tree -nocollision -asgo -precision f64
 run -n 2000 -y 0.002 -tree -precision mixed -norender
+run -n 2000 -y 0.002 -tree -perwave
 echo ALL-OK

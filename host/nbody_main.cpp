@@ -2,7 +2,7 @@
 //
 // The reference is a Go program; no Go toolchain exists where this was written, so the host side is C++ with the
 // reference's flags, its body type, its initial-condition generator and its frame loop:
-//   flags           main.go:17-24   -n -y -state -save -tree -norender -nocollision   (+ -seed -theta -frames-dir -asgo)
+//   flags           main.go:17-24   -n -y -state -save -tree -norender -nocollision   (+ -seed -theta -frames-dir -asgo -perwave)
 //   makebodies      physics.go:16-73 with the two cores of main.go:35-36
 //   frame loop      main.go:80-190  (frames+1 iterations; a frame copy goes to the workers BEFORE each step)
 //   output workers  main.go:50-61   4 consumers behind a queue of capacity 32 (here fed by nbe_frame_stream_begin)
@@ -236,7 +236,7 @@ int main(int argc, char** argv)
     int numbodies = 10;
     double years = 1;
     std::string stateFilename, framesDir = "frames";
-    bool stateSave = false, tree = false, norender = false, nocollision = false, asgo = false;
+    bool stateSave = false, tree = false, norender = false, nocollision = false, asgo = false, perwave = false;
     uint64_t seed = 1;
     double theta = 1;                                        // main.go:73
     int precision = NBE_PREC_F32;
@@ -262,6 +262,7 @@ int main(int argc, char** argv)
         else if (a == "-norender") norender = true;
         else if (a == "-nocollision") nocollision = true;
         else if (a == "-asgo") asgo = true;
+        else if (a == "-perwave") perwave = true;
         else panic("flag provided but not defined: " + a);
     }
 
@@ -306,6 +307,9 @@ int main(int argc, char** argv)
     // -asgo: the tree path with the Go program's own arithmetic (running cell centres tree.go:189-193, last
     // n mod 4 bodies unwalked main.go:134-148), for comparing a run with the reference number for number
     if (asgo && tree) cfg.reference_quirks = NBE_QUIRK_REF_COM | NBE_QUIRK_DROP_TAIL;
+    // -perwave: the bodies of a wavefront open cells together (faster, finer than tree.go:216-217 asks for, not the
+    // reference's interaction set)
+    if (perwave && tree && !asgo) cfg.walk_criterion = NBE_WALK_PER_WAVE;
     nbe_engine* eng = nullptr;
     check(nbe_create(&cfg, &eng));
     const size_t n = bodies.size();
