@@ -252,6 +252,16 @@ def main():
             "interactions_per_s": st9.interactions * 20 / s9,
             "note": "NBE_WALK_PER_WAVE: a cell is opened for all 128 bodies of a wavefront when one of them would open it"}
         e9.close()
+        # ... and at theta = 0.6, where its error against the fp64 direct sum equals the per-body walk's at theta = 0.5
+        # (median 6.2e-4 against 5.8e-4, p99 2.6e-3 against 3.1e-3: profiles/r01_theta_study.txt)
+        e9 = Engine(mode="tree", precision="f32", theta=0.6, device=local, per_wave=True)
+        e9.upload(pw.pos, pw.vel, pw.mass)
+        e9.set_stream(torch.cuda.current_stream().cuda_stream)
+        s9 = timed_steps(lambda: e9.step(1), sync, barrier, 2, 20)
+        extra["bh_theta0.6_fp32_plummer_1M_per_wave_criterion"] = {
+            "ms_per_step": 1e3 * s9 / 20, "steps_per_s": 20 / s9,
+            "note": "same accuracy as the per-body walk at theta 0.5"}
+        e9.close()
         # the headline cloud has equal masses, for which the pair loop leaves the mass out; the same cloud with masses
         # varied by 0.1 % takes the general pair loop (one more packed multiply per pair of interactions)
         pg = physics.plummer(1 << 20, seed=1)
