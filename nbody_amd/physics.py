@@ -181,11 +181,16 @@ class Simulation:
     main.go:104-178 (collisions off); `frame()` is the copy of live bodies taken at main.go:90-101."""
 
     def __init__(self, bodies, tree=False, theta=THETA, dt=DT, eps=0.0, precision="f32", device=0,
-                 bound_width=BOUND_WIDTH, nocollision=True):
+                 bound_width=BOUND_WIDTH, nocollision=True, asgo=False, per_wave=False):
+        """asgo: the Go program's own tree arithmetic (running cell centres tree.go:189-193, last n mod 4 bodies
+        unwalked main.go:134-148); per_wave: the bodies of a wavefront open cells together (faster, finer than the
+        reference's test, not its interaction set).  Both apply to tree mode only."""
         self.bodies = bodies
         self.collisions = not nocollision                     # main.go:24; tree mode only
         self.engine = Engine(mode="tree" if tree else "direct", precision=precision, theta=theta, dt=dt, eps=eps,
-                             bound_width=bound_width, device=device, collisions=self.collisions)
+                             bound_width=bound_width, device=device, collisions=self.collisions,
+                             ref_com=bool(asgo and tree), drop_tail=bool(asgo and tree),
+                             per_wave=bool(per_wave and tree and not asgo))
         self.engine.upload(bodies.pos, bodies.vel, bodies.mass, bodies.ids)
         if self.collisions:
             self.engine.set_radius(bodies.radius)
