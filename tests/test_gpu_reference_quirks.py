@@ -119,3 +119,30 @@ def test_quirks_are_off_by_default_and_refused_in_direct_mode(gpu):
         assert e.cfg.reference_quirks == 0
     with pytest.raises(EngineError):
         Engine(mode="direct", ref_com=True)
+
+
+def test_shards_advance_like_one_engine_with_the_reference_arithmetic(gpu):
+    """Sharded stepping (nbe_set_shard / nbe_shard_prepare / nbe_shard_advance) with both options on: every shard
+    builds the same running centres and leaves the same bodies unwalked as an engine that advances everything."""
+    import torch
+    from nbody_amd.sharded import EngineShard
+    b = physics.makebodies(2001, seed=3)                       # 2003 bodies: 2000, 2001, 2002 are not walked
+
+    def advanced(first, count):
+        with Engine(mode="tree", precision="f64", theta=1.0, ref_com=True, drop_tail=True) as e:
+            e.upload(b.pos, b.vel, b.mass)
+            sh = EngineShard(e)
+            sh.set_shard(first, count)
+            sh.prepare()
+            sh.advance()
+            pos, vel = sh.next_state()
+            torch.cuda.synchronize()
+            out = pos[first:first + count].cpu().numpy().copy(), vel[first:first + count].cpu().numpy().copy()
+            sh.commit()
+            return out
+
+    n = len(b.mass)
+    full_pos, full_vel = advanced(0, n)
+    for first, count in ((0, 700), (700, 650), (1350, n - 1350)):
+        p, v = advanced(first, count)
+        assert np.array_equal(p, full_pos[first:first + count]) and np.array_equal(v, full_vel[first:first + count])
