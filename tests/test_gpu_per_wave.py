@@ -138,3 +138,15 @@ def test_collisions_run_behind_the_per_wave_walk(gpu):
             st = e.stats()
             merges[per_wave] = (st.merges, st.collision_pairs, st.n_alive)
     assert merges[True] == merges[False] and merges[True][0] > 0
+
+
+def test_potential_summed_by_the_per_wave_walk(gpu):
+    """Above 262,144 bodies nbe_energy sums the potential over the nodes the walk accepts: the per-wave walk's sum
+    (finer nodes) agrees with the per-body walk's to the accuracy of either."""
+    b = physics.plummer(300000, seed=6)
+    pe = {}
+    for per_wave in (False, True):
+        with Engine(mode="tree", precision="mixed", theta=0.5, eps=1.0, per_wave=per_wave) as e:
+            e.upload(b.pos, b.vel, b.mass)
+            pe[per_wave] = e.energy()[1]
+    assert pe[True] < 0 and abs(pe[True] - pe[False]) <= 1e-3 * abs(pe[False])
