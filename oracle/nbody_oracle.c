@@ -563,6 +563,82 @@ int orc_forces(long n, const double *mass, const double *pos, unsigned char *ali
     return 0;
 }
 
+/* ---- not in the reference: the opening test of tree.go:216-217 decided per group of bodies -------------------
+ * The engine's optional per-wave walk lets `group` bodies that follow each other in the tree's depth-first leaf order
+ * (children 0..7, tree.go:221-225: the order of their Morton keys) decide together: a cell is opened for all of
+ * them as soon as one of them would open it.  This restates that rule over the pointer octree so that the engine can be
+ * checked against something that shares no code with it.  A body skips its own leaf (tree.go:206-208) and, like the
+ * engine, a body at distance 0 (the reference would produce NaN there). */
+static void collect_leaves(const orc_node *n, long *order, long *k)
+{
+    if (n->totalMass == 0 && n->particle < 0 && n->kind == KIND_EXTERNAL) return;
+    if (n->kind == KIND_EXTERNAL) { if (n->particle >= 0) order[(*k)++] = n->particle; return; }
+    if (n->bucket) { for (long i = 0; i < n->nbucket; i++) collect_leaves(n->bucket[i], order, k); return; }
+    for (int i = 0; i < 8; i++) if (n->children[i]) collect_leaves(n->children[i], order, k);
+}
+
+static long group_gravity(const orc_node *n, orc_body *bodies, const long *members, long cnt, double theta)
+{
+    if (n->totalMass == 0) return 0;
+    if (n->kind == KIND_INTERNAL) {
+        int any_open = 0;
+        for (long m = 0; m < cnt && !any_open; m++) {
+            const orc_body *b = &bodies[members[m]];
+            double d0 = n->centerOfMass[0] - b->X, d1 = n->centerOfMass[1] - b->Y, d2 = n->centerOfMass[2] - b->Z;
+            double r = sqrt(d0 * d0 + d1 * d1 + d2 * d2);
+            if (bound_max(&n->bounds) / r > theta) any_open = 1;      /* tree.go:216-217 for this body */
+        }
+        if (any_open) {
+            long c = 0;
+            if (n->bucket) { for (long i = 0; i < n->nbucket; i++) c += group_gravity(n->bucket[i], bodies, members, cnt, theta); }
+            else { for (int i = 0; i < 8; i++) if (n->children[i]) c += group_gravity(n->children[i], bodies, members, cnt, theta); }
+            return c;
+        }
+    }
+    long c = 0;
+    for (long m = 0; m < cnt; m++) {
+        if (n->particle == members[m]) continue;
+        orc_body *b = &bodies[members[m]];
+        double d0 = n->centerOfMass[0] - b->X, d1 = n->centerOfMass[1] - b->Y, d2 = n->centerOfMass[2] - b->Z;
+        double r = sqrt(d0 * d0 + d1 * d1 + d2 * d2);
+        if (r == 0) continue;
+        double f = ORC_G * (n->totalMass * b->Mass) / (r * r);        /* tree.go:234-238 */
+        b->fx += d0 / r * f; b->fy += d1 / r * f; b->fz += d2 / r * f;
+        c++;
+    }
+    return c;
+}
+
+int orc_forces_group(long n, const double *mass, const double *pos, unsigned char *alive, const orc_params *p, long group,
+                     double *force_out, orc_stats *st)
+{
+    orc_body *bs = (orc_body *)malloc(sizeof(orc_body) * (size_t)(n > 0 ? n : 1));
+    long *order = (long *)malloc(sizeof(long) * (size_t)(n > 0 ? n : 1));
+    orc_stats local; memset(&local, 0, sizeof(local));
+    load_bodies(bs, n, mass, pos, NULL, alive);
+    for (long i = 0; i < n; i++) { bs[i].fx = 0; bs[i].fy = 0; bs[i].fz = 0; }
+    if (n > 0 && group > 0) {
+        orc_tree t; memset(&t, 0, sizeof(t));
+        t.com_mode = p->com_mode; t.max_depth = p->max_depth; t.bodies = bs;
+        nodebound sb;
+        for (int k = 0; k < 3; k++) { sb.center[k] = p->bound_center[k]; sb.width[k] = p->bound_width; }
+        orc_node *root = maketree(&t, n, &sb);
+        long k = 0;
+        collect_leaves(root, order, &k);
+        for (long g0 = 0; g0 < k; g0 += group)
+            local.interactions += group_gravity(root, bs, order + g0, (k - g0 < group ? k - g0 : group), p->theta);
+        local.nodes = t.nnodes;
+        tree_free(&t);
+    }
+    for (long i = 0; i < n; i++) {
+        force_out[3 * i] = bs[i].fx; force_out[3 * i + 1] = bs[i].fy; force_out[3 * i + 2] = bs[i].fz;
+        if (alive) alive[i] = (unsigned char)bs[i].alive;
+    }
+    free(order); free(bs);
+    if (st) *st = local;
+    return 0;
+}
+
 /* Advance the state by nsteps iterations of main.go:104-178.  collide = 0 is the `-nocollision` run; with
  * collide != 0 masses, radii and the live set change too (radius NULL = every body 2, physics.go:20). */
 int orc_step2(long n, double *mass, double *radius, double *pos, double *vel, unsigned char *alive,

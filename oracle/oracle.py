@@ -56,6 +56,7 @@ def lib():
         dp = C.POINTER(C.c_double)
         up = C.POINTER(C.c_ubyte)
         _lib.orc_forces.argtypes = [C.c_long, dp, dp, up, C.POINTER(Params), dp, C.POINTER(Stats)]
+        _lib.orc_forces_group.argtypes = [C.c_long, dp, dp, up, C.POINTER(Params), C.c_long, dp, C.POINTER(Stats)]
         _lib.orc_step.argtypes = [C.c_long, dp, dp, dp, up, C.POINTER(Params), C.c_int, C.POINTER(Stats)]
         lp = C.POINTER(C.c_long)
         _lib.orc_step2.argtypes = [C.c_long, dp, dp, dp, dp, up, C.POINTER(Params), C.c_int, C.c_int, C.POINTER(Stats)]
@@ -110,6 +111,18 @@ def forces(mass, pos, alive=None, **kw):
     out = np.zeros((n, 3), dtype=np.float64)
     st = Stats()
     lib().orc_forces(n, _dp(mass), _dp(pos), _up(alive), C.byref(p), _dp(out), C.byref(st))
+    return out, alive, st
+
+
+def forces_group(mass, pos, group=128, alive=None, **kw):
+    """Forces with the opening test decided per `group` bodies that follow each other in Morton order (the
+    engine's optional per-wave walk; not a reference behaviour).  Returns (force[n,3], alive[n], Stats)."""
+    n, mass, pos, _, alive = _prep(mass, pos, None, alive)
+    kw.setdefault("com_mode", "true"); kw.setdefault("drop_tail", False); kw.setdefault("max_depth", 21)
+    p = make_params(mode="tree", **kw)
+    out = np.zeros((n, 3), dtype=np.float64)
+    st = Stats()
+    lib().orc_forces_group(n, _dp(mass), _dp(pos), _up(alive), C.byref(p), int(group), _dp(out), C.byref(st))
     return out, alive, st
 
 

@@ -150,3 +150,30 @@ def test_potential_summed_by_the_per_wave_walk(gpu):
             e.upload(b.pos, b.vel, b.mass)
             pe[per_wave] = e.energy()[1]
     assert pe[True] < 0 and abs(pe[True] - pe[False]) <= 1e-3 * abs(pe[False])
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_fp64_engine_equals_the_oracles_group_rule(gpu, seed):
+    """The C oracle restates the rule over its own pointer octree (oracle.forces_group: groups of 128 bodies in
+    depth-first leaf order); it shares nothing with the engine.  Random scenes: sizes around the group size,
+    clustered and uniform clouds, bodies outside the bound, theta 0.3 .. 1."""
+    rng = np.random.default_rng(900 + seed)
+    n = int(rng.choice([1, 2, 127, 128, 129, 255, 700, 2000, 5000]))
+    if rng.random() < 0.5:
+        pos = rng.uniform(-3.4e4, 3.4e4, (n, 3))                 # a few outside the 2^16 bound
+    else:
+        c = rng.uniform(-2e4, 2e4, (n // 100 + 1, 3))
+        pos = c[rng.integers(len(c), size=n)] + rng.normal(0, rng.choice([5.0, 300.0]), (n, 3))
+    mass = np.abs(rng.normal(1e4, 5e3, n)) + 1.0
+    theta = float(rng.choice([0.3, 0.5, 0.7, 1.0]))
+    with Engine(mode="tree", precision="f64", theta=theta, per_wave=True) as e:
+        e.upload(pos, np.zeros((n, 3)), mass)
+        acc, alive = e.accel()
+        st = e.stats()
+    f, oalive, ost = O.forces_group(mass, pos, group=128, theta=theta)
+    assert np.array_equal(alive.astype(bool), oalive.astype(bool))
+    live = oalive.astype(bool)
+    assert st.interactions == ost.interactions
+    if live.sum() > 1:
+        ref = f[live] / mass[live, None]
+        assert relerr(acc[live], ref).max() <= 1e-10

@@ -196,3 +196,20 @@ def test_coincident_bodies_and_the_depth_cap_extension():
     assert st.overflow == 0 and alive.all() and st.nodes < 40
     assert abs(-f[2, 0] - want) < 1e-12 * want
     assert np.isnan(f[0]).all() and np.isnan(f[1]).all()
+
+
+def test_group_rule_with_groups_of_one_is_the_per_body_walk():
+    """oracle.forces_group restates the engine's optional per-wave opening rule (not a reference behaviour) over the
+    pointer octree.  With one body per group it must be the reference's own walk, bit for bit; with larger groups
+    every body gets at least as many force evaluations."""
+    rng = np.random.default_rng(3)
+    n = 700
+    pos = rng.normal(0, 4e3, (n, 3)); mass = np.abs(rng.normal(1e3, 500, n)) + 1
+    f1, _, s1 = O.forces(mass, pos, mode="tree", com_mode="true", theta=0.5, drop_tail=False, max_depth=21)
+    g1, _, t1 = O.forces_group(mass, pos, group=1, theta=0.5)
+    assert np.array_equal(f1, g1) and s1.interactions == t1.interactions
+    g128, _, t128 = O.forces_group(mass, pos, group=128, theta=0.5)
+    assert t128.interactions > t1.interactions
+    exact = O.direct_rows(mass, pos)
+    err = lambda f: np.median(np.linalg.norm(f - exact, axis=1) / np.linalg.norm(exact, axis=1))
+    assert err(g128) <= err(g1)
