@@ -198,11 +198,14 @@ def test_steps_can_be_captured_in_a_hip_graph(gpu, mode):
         assert np.array_equal(a, w)
 
 
-@pytest.mark.parametrize("mode,precision", [("tree", "f32"), ("tree", "mixed"), ("direct", "f32")])
-def test_single_rank_rccl_stepper_with_overlapped_velocity_exchange(gpu, mode, precision):
+@pytest.mark.parametrize("mode,precision,extra", [("tree", "f32", {}), ("tree", "mixed", {}), ("direct", "f32", {}),
+                                                  ("tree", "f32", {"per_wave": True}),
+                                                  ("tree", "f64", {"ref_com": True, "drop_tail": True})])
+def test_single_rank_rccl_stepper_with_overlapped_velocity_exchange(gpu, mode, precision, extra):
     """The RCCL path of ShardedStepper on one GPU (one-rank "nccl" group, collectives forced): positions are
     exchanged first, the velocity exchange runs beside the next step's key sort (nbe_shard_sort), and the result
-    equals plain nbe_step bit for bit."""
+    equals plain nbe_step bit for bit; also with the per-wave walk and with the reference's own arithmetic (whose
+    build borrows a buffer of the sort that runs ahead)."""
     import torch
     import torch.distributed as dist
     from nbody_amd.sharded import EngineShard, ShardedStepper
@@ -216,11 +219,11 @@ def test_single_rank_rccl_stepper_with_overlapped_velocity_exchange(gpu, mode, p
             pytest.skip(f"cannot create a one-rank RCCL group here: {ex}")
     try:
         b = physics.plummer(20000, seed=8, a=3e3)
-        with Engine(mode=mode, precision=precision, theta=0.6) as plain:
+        with Engine(mode=mode, precision=precision, theta=0.6, **extra) as plain:
             plain.upload(b.pos, b.vel, b.mass)
             plain.step(6)
             want = plain.download()
-        with Engine(mode=mode, precision=precision, theta=0.6) as e:
+        with Engine(mode=mode, precision=precision, theta=0.6, **extra) as e:
             e.upload(b.pos, b.vel, b.mass)
             st = ShardedStepper(EngineShard(e, device_index=0), rank=0, world=1, always_gather=True)
             assert st.backend == "nccl"
