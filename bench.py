@@ -220,6 +220,20 @@ def main():
                 "ms_sort": st3.ms_sort, "ms_build": st3.ms_build, "ms_force": st3.ms_force,
                 "sort_algorithmic_GBps": m * 200.0 / (st3.ms_sort * 1e-3) / 1e9 if st3.ms_sort > 0 else None,
                 "build_algorithmic_GBps": m * 130.0 / (st3.ms_build * 1e-3) / 1e9 if st3.ms_build > 0 else None})
+        if world > 1 or force_dist:
+            # where a sharded step spends its time (phases run one after the other, exchanges blocking; maximum over
+            # the ranks): the replicated build, the own range's forces, the two all-gathers
+            prof = ShardedStepper(EngineShard(e3, device_index=local), always_gather=force_dist)
+            prof.step_profiled()
+            acc = {}
+            for _ in range(3):
+                for k, v in prof.step_profiled().items():
+                    acc[k] = acc.get(k, 0.0) + v / 3
+            if world > 1:
+                t = torch.tensor([acc[k] for k in sorted(acc)], device="cuda", dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                acc = {k: float(v) for k, v in zip(sorted(acc), t.tolist())}
+            extra["bh_theta0.5_fp32_plummer_16M"]["sharded_phase_ms"] = acc
         e3.close()
         # the same cloud with the opening test taken per wavefront of 128 bodies (finer than the reference's per-body
         # test, not its interaction set; off by default), also on every GPU count

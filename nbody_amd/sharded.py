@@ -141,3 +141,23 @@ class ShardedStepper:
             if pending is not None:
                 self.shard.sort_ahead()
                 pending.wait()          # a stream dependency, not a host wait
+
+    def step_profiled(self):
+        """One step with every phase bracketed by events on the compute stream and the exchanges run blocking, one
+        after the other (no overlap): returns the milliseconds of build (sort + tree, replicated), advance (forces +
+        update of the own range), the position exchange and the velocity exchange.  For diagnosis only."""
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+        ev[0].record()
+        self.shard.prepare()
+        ev[1].record()
+        self.shard.advance()
+        ev[2].record()
+        pos, vel = self.shard.next_state()
+        self._gather(pos)
+        ev[3].record()
+        self._gather(vel)
+        ev[4].record()
+        self.shard.commit()
+        torch.cuda.synchronize()
+        names = ("build", "advance", "gather_positions", "gather_velocities")
+        return {n: ev[k].elapsed_time(ev[k + 1]) for k, n in enumerate(names)}
