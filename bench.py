@@ -174,9 +174,22 @@ def main():
                 "achieved": achieved, "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_VALU_PEAK_TFLOPS,
                 "traffic": traffic_from_profiles(workload), "kernel_ms": kernel_ms,
                 "flop_per_interaction": FLOP_PER_INTERACTION}
+    extra = {}
+    if world > 1 or force_dist:
+        # the headline step phase by phase (exchanges blocking, maximum over the ranks)
+        prof = ShardedStepper(EngineShard(eng, device_index=local), always_gather=force_dist)
+        prof.step_profiled()
+        acc = {}
+        for _ in range(2):
+            for k, v in prof.step_profiled().items():
+                acc[k] = acc.get(k, 0.0) + v / 2
+        if world > 1:
+            t = torch.tensor([acc[k] for k in sorted(acc)], device="cuda", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            acc = {k: float(v) for k, v in zip(sorted(acc), t.tolist())}
+        extra["headline_sharded_phase_ms"] = acc
     eng.close()
 
-    extra = {}
     if not args.no_extra:
         other = "tree" if headline_mode == "direct" else "direct"
         m = 1 << 20
