@@ -17,6 +17,10 @@
 #include "engine_internal.h"
 #include "tree_keys.h"
 
+// tw.counters[COUNTER_SORTED_ALIVE]: live bodies found by the last key sort; becomes counters[0] when the state is
+// reordered (permute_kernel)
+#define COUNTER_SORTED_ALIVE 8
+
 #define SORT_KPT 8                     // keys per thread
 #define SORT_TILE (256 * SORT_KPT)     // keys per workgroup
 #define SCAN_TILE 2048                 // elements per workgroup in the device-wide scan (256 threads x 8)
@@ -437,7 +441,7 @@ __global__ __launch_bounds__(1024) void small_sort_kernel(const R4* __restrict__
     if (tid == 0) {
         uint32_t tot = 0;
         for (int w = 0; w < SMALL_WAVES; w++) tot += wsum[w];
-        counters[0] = (int)tot;
+        counters[COUNTER_SORTED_ALIVE] = (int)tot;
     }
 }
 
@@ -448,9 +452,15 @@ __global__ __launch_bounds__(256) void permute_kernel(const uint32_t* __restrict
                                                       const float4* __restrict__ mirror_in, const double* __restrict__ radius_in,
                                                       S4* __restrict__ pos_out, S4* __restrict__ vel_out,
                                                       uint32_t* __restrict__ orig_out, float4* __restrict__ mirror_out,
-                                                      double* __restrict__ radius_out)
+                                                      double* __restrict__ radius_out, int* __restrict__ counters)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i == 0) {
+        // The sort left its live count aside (it may have run ahead, while the state was still in the previous
+        // order and counters[0..3] still described that order); from here on the state is in the new order.
+        counters[0] = counters[COUNTER_SORTED_ALIVE];
+        counters[1] = 0; counters[2] = 0; counters[3] = 0;
+    }
     if (i >= n) return;
     const uint32_t j = idx[i];
     pos_out[i] = pos_in[j];
@@ -1007,7 +1017,6 @@ static int sort_keys_t(nbe_engine* e)
     const double W = e->cfg.bound_width;
     const double lox = e->cfg.bound_center[0] - 0.5 * W, loy = e->cfg.bound_center[1] - 0.5 * W,
                  loz = e->cfg.bound_center[2] - 0.5 * W;
-    NBE_HIP(hipMemsetAsync(w.counters, 0, 4 * sizeof(int), e->stream));
     if (n <= e->small_max) {
         hipLaunchKernelGGL((small_sort_kernel<R4>), dim3(1), dim3(1024), 0, e->stream, force_pos, n, lox, loy, loz, W, w.keys[0],
                            w.sidx[0], w.counters);
@@ -1027,7 +1036,7 @@ static int sort_keys_t(nbe_engine* e)
         hipLaunchKernelGGL(scan_rows_kernel, dim3(256), dim3(256), 0, e->stream, w.block_hist, nblocks, w.scan_tmp);
         hipLaunchKernelGGL(radix_scatter_kernel, dim3(nblocks), dim3(256), 0, e->stream, w.keys[in], w.sidx[in],
                            w.keys[in ^ 1], w.sidx[in ^ 1], w.block_hist, w.scan_tmp, n, shift, nblocks,
-                           pass == 7 ? w.counters : (int*)nullptr);
+                           pass == 7 ? w.counters + COUNTER_SORTED_ALIVE : (int*)nullptr);
         NBE_HIP(hipGetLastError());
         in ^= 1;
     }
@@ -1051,7 +1060,7 @@ static int sort_and_build_t(nbe_engine* e)
     hipLaunchKernelGGL((permute_kernel<S4>), dim3(nb), dim3(256), 0, e->stream, w.sidx[0], n, (const S4*)e->posm[cur],
                        (const S4*)e->vel[cur], e->orig[e->orig_cur], mixed ? e->mirror[cur] : (const float4*)nullptr,
                        (const double*)e->radius[cur], (S4*)e->posm[nxt], (S4*)e->vel[nxt], e->orig[e->orig_cur ^ 1],
-                       mixed ? e->mirror[nxt] : (float4*)nullptr, e->radius[nxt]);
+                       mixed ? e->mirror[nxt] : (float4*)nullptr, e->radius[nxt], w.counters);
     NBE_HIP(hipGetLastError());
     e->cur = nxt;
     e->orig_cur ^= 1;

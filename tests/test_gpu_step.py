@@ -238,6 +238,36 @@ def test_single_rank_rccl_stepper_with_overlapped_velocity_exchange(gpu, mode, p
             dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("n", [3000, 20000])
+def test_sort_running_ahead_does_not_change_who_is_alive(gpu, n):
+    """nbe_shard_sort sorts the keys of the next step while the state is still in the previous order.  A body that
+    has just left the bound is found by that sort; until the state is reordered, downloads, energies and frames must
+    keep describing the previous order: same survivors as an engine that has not sorted ahead."""
+    b = physics.plummer(n, seed=4, a=2e3)                                # truncated at 24 km: all inside the bound
+    pos, vel = b.pos.copy(), b.vel.copy()
+    pos[17] = (32767.0, 10.0, -5.0); vel[17] = (1.0, 0.0, 0.0)          # leaves through the +x face in the first step
+    with Engine(mode="tree", precision="f32", theta=0.6, eps=1.0) as plain, Engine(mode="tree", precision="f32", theta=0.6, eps=1.0) as e:
+        for eng in (plain, e):
+            eng.upload(pos, vel, b.mass)
+        plain.step(1)
+        e.shard_prepare(); e.shard_advance(); e.shard_commit()
+        e.shard_sort()                                                   # finds n - 1 live bodies, state still unsorted
+        want, got = plain.download(), e.download()
+        assert len(want[0]) == n
+        for a, w in zip(got, want):
+            assert np.array_equal(a, w)
+        ew, eg = plain.energy(), e.energy()
+        # (block sums are added with atomics: the last bits depend on their order)
+        assert abs(ew[0] - eg[0]) <= 1e-12 * ew[0] and abs(ew[1] - eg[1]) <= 1e-12 * abs(ew[1])
+        assert np.abs(ew[2] - eg[2]).max() <= 1e-12 * (b.mass * np.linalg.norm(vel, axis=1)).sum()
+        plain.step(1)
+        e.shard_prepare(); e.shard_advance(); e.shard_commit()
+        want, got = plain.download(), e.download()
+        assert len(want[0]) == n - 1 and 17 not in want[3]
+        for a, w in zip(got, want):
+            assert np.array_equal(a, w)
+
+
 def test_two_engines_in_one_process_do_not_share_state(gpu):
     """Engines own their streams and workspaces: two of them stepped in turn give what each gives alone."""
     b1 = physics.makebodies(1500, seed=1); b2 = physics.plummer(2500, seed=2)
