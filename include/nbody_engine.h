@@ -210,6 +210,22 @@ int nbe_tree_nodes(nbe_engine *e, double *out, size_t cap, size_t *count);
  * per launch. */
 int nbe_time_force_kernel(nbe_engine *e, int reps, float *ms_per_launch);
 
+/* ---- force pass that allocates nothing ----
+ * No counterpart in the reference.  For callers that cannot allocate device memory: code under HIP graph capture,
+ * tight serving loops, harnesses that forbid hipMalloc.  It is the force pass of nbe_accel for the fp32 direct sum
+ * (main.go:105-128 without the update loop) on arrays the caller owns: d_pos_mass holds n x (x, y, z, mass) as fp32 in
+ * device memory, d_acc receives n x (ax, ay, az, 0) as fp32 in device memory (a = f/m), both on HIP device `device`;
+ * the kernels are queued on `hip_stream` (a hipStream_t; NULL = the default stream) and the call returns without
+ * waiting.  eps is the softening of nbe_config (0 = the reference's force), G the gravitational constant.
+ * The partial sums that nbe_accel keeps in an allocated buffer live in a fixed 20 MiB array in device memory that
+ * each GPU holds from the library's first use on it until the process ends; hence at most 262,144 bodies
+ * (NBE_E_UNSUPPORTED beyond), and two calls that overlap in time on one GPU (different streams or threads) race on
+ * that array: issue them on one stream, or one after the other.  No hipMalloc, hipFree or other allocating call is
+ * made, on the device or the host.  Results equal nbe_accel's for the same bodies bit for bit when the masses are
+ * not all equal (nbe_accel switches to a kernel without the mass factor for equal masses: same values to rounding). */
+int nbe_accel_direct_noalloc(int device, void *hip_stream, size_t n, const float *d_pos_mass, float *d_acc, double G,
+                             double eps);
+
 #ifdef __cplusplus
 }
 #endif

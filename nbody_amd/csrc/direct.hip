@@ -12,6 +12,7 @@
 // so rsq stays finite and is multiplied by dx = 0 or m = 0.
 #include "engine_internal.h"
 #include "kernels_common.h"
+#include <cmath>
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
@@ -251,6 +252,23 @@ template <typename A, int ITILE, int BLOCK, int OUT> struct DirectKernel<float, 
     }
 };
 
+// How a launch over nt targets and n sources splits the source range across blockIdx.y: aim for >= 16 waves per CU
+// when the targets alone are too few.  *jchunk sources (a multiple of the tile) go to each of *jsplit slices.
+static void direct_split(size_t n, size_t nt, int block, int itile, unsigned* jsplit_out, size_t* jchunk_out)
+{
+    const unsigned iblocks = cdiv(nt, (size_t)block * itile);
+    const unsigned want_blocks = 4096 * 64 / block;
+    unsigned jsplit = 1;
+    if (iblocks < want_blocks) jsplit = cdiv(want_blocks, iblocks);
+    const unsigned jtiles = cdiv(n, DIRECT_TILE);
+    if (jsplit > jtiles) jsplit = jtiles;
+    if (jsplit > 64) jsplit = 64;
+    if (jsplit < 1) jsplit = 1;
+    const size_t jchunk = (size_t)cdiv(cdiv(n, jsplit), DIRECT_TILE) * DIRECT_TILE;
+    *jsplit_out = cdiv(n, jchunk);
+    *jchunk_out = jchunk;
+}
+
 template <typename R, typename A, int ITILE, int BLOCK>
 static int launch_direct(nbe_engine* e, const void* src, uint64_t t0, uint64_t t1, bool fused, int src_buf, int dst_buf)
 {
@@ -260,15 +278,9 @@ static int launch_direct(nbe_engine* e, const void* src, uint64_t t0, uint64_t t
     if (nt == 0) return NBE_OK;
     if (n > 0x7fffffffull) { nbe_set_error("direct sum supports at most 2^31-1 bodies"); return NBE_E_UNSUPPORTED; }
     const unsigned iblocks = cdiv(nt, BLOCK * ITILE);
-    // Aim for >= 16 waves per CU; split the source range across blockIdx.y when targets alone are too few.
-    const unsigned want_blocks = 4096 * 64 / BLOCK;
-    unsigned jsplit = 1;
-    if (iblocks < want_blocks) jsplit = cdiv(want_blocks, iblocks);
-    const unsigned jtiles = cdiv(n, DIRECT_TILE);
-    if (jsplit > jtiles) jsplit = jtiles;
-    if (jsplit > 64) jsplit = 64;
-    size_t jchunk = (size_t)cdiv(cdiv(n, jsplit), DIRECT_TILE) * DIRECT_TILE;
-    jsplit = cdiv(n, jchunk);
+    unsigned jsplit;
+    size_t jchunk;
+    direct_split(n, nt, BLOCK, ITILE, &jsplit, &jchunk);
 
     const double eps = e->cfg.eps;
     const double tiny = __is_same(R, float) ? 1e-12 : 1e-60;
@@ -332,4 +344,81 @@ int direct_forces(nbe_engine* e, int src_buf, uint64_t t0, uint64_t t1, bool fus
     }
     nbe_set_error("unknown precision %d", e->cfg.precision);
     return NBE_E_INVALID;
+}
+
+// ---- force pass for callers that cannot allocate ------------------------------------------------------------
+// nbe_accel_direct_noalloc: the fp32 direct-sum force pass of nbe_accel on caller-owned device arrays, for callers
+// that must not allocate (HIP graph capture, serving loops).  The only memory the pass needs beyond its input and
+// output is the array of partial sums that a launch with few targets spreads over slices of the source range
+// (direct_split); it lives in a fixed array in device memory instead of a hipMalloc'd buffer.  Every GPU the library
+// is used on holds its own copy of the array until the process ends.
+#define NOALLOC_MAX_BODIES 262144u
+// slices * targets <= 4096 * 256 + targets for any body count (direct_split), hence this many partial sums at most
+#define NOALLOC_SCRATCH_ELEMS ((1u << 20) + NOALLOC_MAX_BODIES)
+static __device__ __align__(256) float4 scratch[NOALLOC_SCRATCH_ELEMS];
+
+// Device address of `scratch` on each GPU, looked up once per device with that device current.  In host code the
+// array's name is only a handle for hipGetSymbolAddress: it must never be handed to a kernel or a memset.
+#define NOALLOC_MAX_DEVICES 64
+static float4* g_scratch_ptr[NOALLOC_MAX_DEVICES];
+static std::mutex g_scratch_mu;
+
+static int scratch_for_device(int device, float4** out)
+{
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    if (!g_scratch_ptr[device]) {
+        void* p = nullptr;
+        NBE_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        if (!p) { nbe_set_error("hipGetSymbolAddress returned no address for the scratch array"); return NBE_E_DEVICE; }
+        g_scratch_ptr[device] = (float4*)p;
+    }
+    *out = g_scratch_ptr[device];
+    return NBE_OK;
+}
+
+extern "C" int nbe_accel_direct_noalloc(int device, void* hip_stream, size_t n, const float* d_pos_mass, float* d_acc,
+                                        double G, double eps)
+{
+    if (n == 0) return NBE_OK;
+    if (!d_pos_mass || !d_acc) { nbe_set_error("nbe_accel_direct_noalloc: NULL device array"); return NBE_E_INVALID; }
+    if (n > NOALLOC_MAX_BODIES) {
+        nbe_set_error("nbe_accel_direct_noalloc takes at most %u bodies (got %zu): its partial sums live in a fixed %zu-byte "
+                      "device array; use an engine (nbe_create, nbe_accel) for more",
+                      NOALLOC_MAX_BODIES, n, sizeof(float4) * (size_t)NOALLOC_SCRATCH_ELEMS);
+        return NBE_E_UNSUPPORTED;
+    }
+    if (!(eps >= 0.0) || !std::isfinite(G)) { nbe_set_error("nbe_accel_direct_noalloc: eps must be >= 0 and G finite"); return NBE_E_INVALID; }
+    if (device < 0 || device >= NOALLOC_MAX_DEVICES) { nbe_set_error("device %d out of range", device); return NBE_E_INVALID; }
+    NBE_HIP(hipSetDevice(device));
+    float4* part = nullptr;
+    NBE_TRY(scratch_for_device(device, &part));
+    constexpr int ITILE = DIRECT_ITILE, BLOCK = 64;
+    unsigned jsplit;
+    size_t jchunk;
+    direct_split(n, n, BLOCK, ITILE, &jsplit, &jchunk);
+    if ((size_t)jsplit * n > NOALLOC_SCRATCH_ELEMS) { nbe_set_error("internal: %u slices of %zu targets exceed the scratch array", jsplit, n); return NBE_E_INVALID; }
+    const float floor2 = (float)(eps * eps > 1e-12 ? eps * eps : 1e-12);
+    const float Gf = (float)G;
+    hipStream_t stream = (hipStream_t)hip_stream;
+    const float4* src = (const float4*)d_pos_mass;
+    float4* acc = (float4*)d_acc;
+    const unsigned iblocks = cdiv(n, (size_t)BLOCK * ITILE);
+    if (jsplit == 1) {
+        hipLaunchKernelGGL((direct_kernel_f32<float, ITILE, BLOCK, OUT_ACC, false>), dim3(iblocks, 1), dim3(BLOCK), 0, stream, src,
+                           (int)n, 0, (int)n, (int)jchunk, floor2, Gf, 0.0f, acc, (const float4*)nullptr, (const float4*)nullptr,
+                           (float4*)nullptr, (float4*)nullptr, (float4*)nullptr);
+        NBE_HIP(hipGetLastError());
+        return NBE_OK;
+    }
+    // every partial sum [slice][target] is written by the first launch before the second reads it, so what an
+    // earlier call left in the array never shows
+    hipLaunchKernelGGL((direct_kernel_f32<float, ITILE, BLOCK, OUT_PARTIAL, false>), dim3(iblocks, jsplit), dim3(BLOCK), 0, stream,
+                       src, (int)n, 0, (int)n, (int)jchunk, floor2, Gf, 0.0f, part, (const float4*)nullptr, (const float4*)nullptr,
+                       (float4*)nullptr, (float4*)nullptr, (float4*)nullptr);
+    NBE_HIP(hipGetLastError());
+    hipLaunchKernelGGL((direct_finish_kernel<float, false>), dim3(cdiv(n, 256)), dim3(256), 0, stream, (const float4*)part,
+                       (int)jsplit, 0, (int)n, Gf, 0.0f, acc, (const float4*)nullptr, (const float4*)nullptr, (float4*)nullptr,
+                       (float4*)nullptr, (float4*)nullptr);
+    NBE_HIP(hipGetLastError());
+    return NBE_OK;
 }

@@ -20,7 +20,7 @@ EXPORTS = ("nbe_default_config", "nbe_create", "nbe_destroy", "nbe_last_error", 
            "nbe_accel", "nbe_step", "nbe_step_timed", "nbe_sync", "nbe_stats", "nbe_energy", "nbe_set_shard",
            "nbe_shard_prepare", "nbe_shard_advance", "nbe_shard_commit", "nbe_device_state", "nbe_set_stream",
            "nbe_time_force_kernel", "nbe_tree_nodes", "nbe_frame_stream_begin", "nbe_frame_stream_end",
-           "nbe_set_radius", "nbe_get_radius", "nbe_shard_sort")
+           "nbe_set_radius", "nbe_get_radius", "nbe_shard_sort", "nbe_accel_direct_noalloc")
 
 FRAME_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_size_t, C.POINTER(C.c_float), C.POINTER(C.c_float),
                        C.POINTER(C.c_uint64))
@@ -100,6 +100,7 @@ def load_library():
     lib.nbe_frame_stream_end.argtypes = [vp]
     lib.nbe_set_radius.argtypes = [vp, dp]
     lib.nbe_get_radius.argtypes = [vp, dp, C.POINTER(C.c_size_t)]
+    lib.nbe_accel_direct_noalloc.argtypes = [C.c_int, vp, C.c_size_t, vp, vp, C.c_double, C.c_double]
     for name in EXPORTS:
         if name not in ("nbe_destroy", "nbe_last_error"):
             getattr(lib, name).restype = C.c_int
@@ -296,3 +297,13 @@ class Engine:
 
     def set_stream(self, hip_stream):
         self._check(self._lib.nbe_set_stream(self._h, C.c_void_p(hip_stream)))
+
+
+def accel_direct_noalloc(device, hip_stream, n, d_pos_mass, d_acc, G=6.67408e-11, eps=0.0):
+    """nbe_accel_direct_noalloc: fp32 direct-sum accelerations of n bodies from device pointer d_pos_mass
+    (n x 4 fp32: x, y, z, mass) into device pointer d_acc (n x 4 fp32), queued on hip_stream; allocates nothing."""
+    lib = load_library()
+    rc = lib.nbe_accel_direct_noalloc(int(device), C.c_void_p(hip_stream), int(n), C.c_void_p(d_pos_mass),
+                                      C.c_void_p(d_acc), float(G), float(eps))
+    if rc != 0:
+        raise EngineError(f"nbody_engine error {rc}: {lib.nbe_last_error().decode()}")
