@@ -22,9 +22,16 @@ import (
 	"unsafe"
 )
 
+// The precision constants as Go values (gpustep.go has no cgo preamble of its own).
+const (
+	nbePrecF32   = C.NBE_PREC_F32
+	nbePrecMixed = C.NBE_PREC_MIXED
+	nbePrecF64   = C.NBE_PREC_F64
+)
+
 // gpuOptions are the engine's choices the reference has no flag for.
 type gpuOptions struct {
-	precision int  // C.NBE_PREC_F32 (default), C.NBE_PREC_MIXED, C.NBE_PREC_F64
+	precision int  // C.NBE_PREC_F64 (the reference computes in float64; gpuOptionsFromFlags' default), C.NBE_PREC_MIXED, C.NBE_PREC_F32
 	asGo      bool // tree mode: running cell centres (tree.go:189-193) and unwalked last n mod 4 bodies (main.go:134-148)
 	perWave   bool // tree mode: the bodies of a wavefront open cells together (faster, finer, not the reference's set)
 }
@@ -41,6 +48,7 @@ type gpuEngine struct {
 	id      []uint64
 	radByID map[uint64]float64 // radii of an engine without collisions (they never change there)
 	collide bool
+	streamToken uintptr // key of this engine's frame stream (framestream.go)
 }
 
 func gpuCheck(rc C.int) {

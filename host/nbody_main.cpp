@@ -2,7 +2,9 @@
 //
 // The reference is a Go program; no Go toolchain exists where this was written, so the host side is C++ with the
 // reference's flags, its body type, its initial-condition generator and its frame loop:
-//   flags           main.go:17-24   -n -y -state -save -tree -norender -nocollision   (+ -seed -theta -frames-dir -asgo -perwave)
+//   flags           main.go:17-24   -n -y -state -save -tree -norender -nocollision
+//                   (+ -seed -frames-dir -precision -asgo -perwave, and the reference's compile-time constants as
+//                   run-time values: -theta main.go:73, -dt main.go:28, -bound main.go:74-76, -eps softening, -G physics.go:132)
 //   makebodies      physics.go:16-73 with the two cores of main.go:35-36
 //   frame loop      main.go:80-190  (frames+1 iterations; a frame copy goes to the workers BEFORE each step)
 //   output workers  main.go:50-61   4 consumers behind a queue of capacity 32 (here fed by nbe_frame_stream_begin)
@@ -21,11 +23,13 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <filesystem>
 #include <memory>
 #include <mutex>
 #include <random>
 #include <string>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include "gob.hpp"
@@ -203,7 +207,7 @@ static void frameToFiles(const std::string& dir, FrameQueue* ch)
 
 struct StreamCtx {
     FrameQueue* ch;
-    const std::vector<double>* radius_by_id;   // used when the engine sends no radii (collisions off: they never change)
+    const std::unordered_map<uint64_t, double>* radius_by_id;   // used when the engine sends no radii (collisions off: they never change)
     std::mutex mu;
     std::unique_ptr<frameJob> last;            // lastFrame of main.go:97-100
     int remaining = 0;
@@ -221,7 +225,10 @@ static void on_frame(void* user, int frame, size_t n, const float* xyzm, const f
         b.ID = ids[k];
         b.X = xyzm[4 * k]; b.Y = xyzm[4 * k + 1]; b.Z = xyzm[4 * k + 2]; b.Mass = xyzm[4 * k + 3];
         if (radius) b.Radius = radius[k];
-        else b.Radius = ids[k] < ctx->radius_by_id->size() ? (*ctx->radius_by_id)[ids[k]] : 2.0;
+        else {
+            const auto it = ctx->radius_by_id->find(ids[k]);
+            b.Radius = it != ctx->radius_by_id->end() ? it->second : 2.0;
+        }
     }
     {
         std::lock_guard<std::mutex> lk(ctx->mu);
@@ -239,6 +246,8 @@ int main(int argc, char** argv)
     bool stateSave = false, tree = false, norender = false, nocollision = false, asgo = false, perwave = false;
     uint64_t seed = 1;
     double theta = 1;                                        // main.go:73
+    double dt = 60 * 60;                                     // main.go:28
+    double eps = 0, bound = 65536, gconst = G;               // no softening; simbound main.go:74-76; physics.go:132
     int precision = NBE_PREC_F32;
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
@@ -254,6 +263,10 @@ int main(int argc, char** argv)
         else if (const char* v = val("-state")) stateFilename = v;
         else if (const char* v = val("-seed")) seed = std::strtoull(v, nullptr, 10);
         else if (const char* v = val("-theta")) theta = std::atof(v);
+        else if (const char* v = val("-dt")) dt = std::atof(v);
+        else if (const char* v = val("-eps")) eps = std::atof(v);
+        else if (const char* v = val("-bound")) bound = std::atof(v);
+        else if (const char* v = val("-G")) gconst = std::atof(v);
         else if (const char* v = val("-frames-dir")) framesDir = v;
         else if (const char* v = val("-precision")) precision = !std::strcmp(v, "f64") ? NBE_PREC_F64 : !std::strcmp(v, "mixed") ? NBE_PREC_MIXED : NBE_PREC_F32;
         else if (const char* v = val("-recode")) { exportFrameData(importFrameData(v)); return 0; }
@@ -266,7 +279,6 @@ int main(int argc, char** argv)
         else panic("flag provided but not defined: " + a);
     }
 
-    const int dt = 60 * 60;                                  // main.go:28
     const int iterPerFrame = 1;                              // main.go:29
     int frames = (int)(years * 365 * 24) / iterPerFrame;     // main.go:30
     body c0, c1;                                             // main.go:35-36
@@ -288,12 +300,13 @@ int main(int argc, char** argv)
     const int workers = 4;                                   // main.go:51
     std::vector<std::thread> wg;
     if (!norender) {
-        std::string cmd = "mkdir -p '" + framesDir + "'";
-        if (std::system(cmd.c_str()) != 0) panic("cannot create " + framesDir);
+        std::error_code ec;
+        std::filesystem::create_directories(framesDir, ec);
+        if (ec) panic("cannot create " + framesDir + ": " + ec.message());
         for (int i = 0; i < workers; i++) wg.emplace_back(frameToFiles, framesDir, &ch);
     }
 
-    std::printf("render: %s\ncollisions: %s\ntree: %s\nbodies: %zu\nstep: %d sec\nframes: %d\nsimulation time: %.1f days\n",
+    std::printf("render: %s\ncollisions: %s\ntree: %s\nbodies: %zu\nstep: %g sec\nframes: %d\nsimulation time: %.1f days\n",
                 norender ? "false" : "true", nocollision ? "false" : "true", tree ? "true" : "false", bodies.size(), dt,
                 frames - startFrame, (double)dt * iterPerFrame * (frames - startFrame) / 3600.0 / 24.0);   // main.go:64-71
 
@@ -302,6 +315,9 @@ int main(int argc, char** argv)
     cfg.mode = tree ? NBE_MODE_TREE : NBE_MODE_DIRECT;
     cfg.theta = theta;
     cfg.dt = dt;
+    cfg.eps = eps;
+    cfg.bound_width = bound;
+    cfg.G = gconst;
     cfg.precision = precision;
     cfg.collisions = nocollision ? 0 : 1;                    // main.go:24
     // -asgo: the tree path with the Go program's own arithmetic (running cell centres tree.go:189-193, last
@@ -313,14 +329,15 @@ int main(int argc, char** argv)
     nbe_engine* eng = nullptr;
     check(nbe_create(&cfg, &eng));
     const size_t n = bodies.size();
-    std::vector<double> pos(3 * n), vel(3 * n), mass(n), radius_by_id;
+    std::vector<double> pos(3 * n), vel(3 * n), mass(n);
+    std::unordered_map<uint64_t, double> radius_by_id;     // IDs of a -state file are arbitrary 64-bit values
+    radius_by_id.reserve(n);
     std::vector<uint64_t> id(n);
     for (size_t k = 0; k < n; k++) {
         const body& b = bodies[k];
         pos[3 * k] = b.X; pos[3 * k + 1] = b.Y; pos[3 * k + 2] = b.Z;
         vel[3 * k] = b.Vx; vel[3 * k + 1] = b.Vy; vel[3 * k + 2] = b.Vz;
         mass[k] = b.Mass; id[k] = b.ID;
-        if (b.ID >= radius_by_id.size()) radius_by_id.resize(b.ID + 1, 2.0);
         radius_by_id[b.ID] = b.Radius;
     }
     check(nbe_upload(eng, n, pos.data(), vel.data(), mass.data(), id.data()));
@@ -373,7 +390,8 @@ int main(int argc, char** argv)
         for (size_t k = 0; k < alive; k++) {
             body& b = fin.Bodies[k];
             b.ID = id[k]; b.Mass = mass[k];
-            b.Radius = cfg.collisions ? radius[k] : id[k] < radius_by_id.size() ? radius_by_id[id[k]] : 2.0;
+            const auto it = radius_by_id.find(id[k]);
+            b.Radius = cfg.collisions ? radius[k] : it != radius_by_id.end() ? it->second : 2.0;
             b.X = pos[3 * k]; b.Y = pos[3 * k + 1]; b.Z = pos[3 * k + 2];
             b.Vx = vel[3 * k]; b.Vy = vel[3 * k + 1]; b.Vz = vel[3 * k + 2];
         }

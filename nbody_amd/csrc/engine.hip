@@ -552,7 +552,8 @@ extern "C" int nbe_step_timed(nbe_engine* e, nbe_stats_t* stats)
     if (!e) { nbe_set_error("engine is NULL"); return NBE_E_INVALID; }
     NBE_TRY(use_device(e));
     if (e->n == 0) { if (stats) *stats = e->stats; return NBE_OK; }
-    if (e->advance_pending || e->prepared) { nbe_set_error("nbe_step_timed inside a sharded step"); return NBE_E_INVALID; }
+    if (e->advance_pending) { nbe_set_error("nbe_step_timed between nbe_shard_advance and nbe_shard_commit"); return NBE_E_INVALID; }
+    // a tree left by nbe_accel, nbe_energy or nbe_tree_nodes is reused: sort and build then read as 0 ms
     e->timing = true;
     int rc = step_once_full(e);
     e->timing = false;

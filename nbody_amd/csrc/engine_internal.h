@@ -119,6 +119,8 @@ struct FrameStream {
     bool active = false;
     int every = 1, first_frame = 0;
     uint64_t step_base = 0;       // stats.steps when streaming began
+    uint64_t last_k = 0;          // step (counted from step_base) whose frame went out last
+    bool have_last = false;
     nbe_frame_cb cb = nullptr;
     void* user = nullptr;
     hipStream_t side = nullptr;

@@ -51,9 +51,11 @@ static void delivery_loop(nbe_engine* e)
         } else if (e->cfg.collisions) {
             // bodies absorbed by a collision since the last build are parked outside the bound without mass:
             // leave them out, as the nil check at main.go:91-95 does
+            // (the parking position, in the very expression collide_and_update forms it with, so that both round alike
+            // for any bound; it lies outside the bound, where no live body of a built tree can be)
             const double W = e->cfg.bound_width;
-            const float px = (float)(e->cfg.bound_center[0] + 1.5 * W), py = (float)(e->cfg.bound_center[1] + 1.5 * W),
-                        pz = (float)(e->cfg.bound_center[2] + 1.5 * W);
+            const float px = (float)((e->cfg.bound_center[0] - 0.5 * W) + 2.0 * W), py = (float)((e->cfg.bound_center[1] - 0.5 * W) + 2.0 * W),
+                        pz = (float)((e->cfg.bound_center[2] - 0.5 * W) + 2.0 * W);
             size_t k = 0;
             for (size_t d = 0; d < na; d++) {
                 const float* r = s.xyzm + 4 * d;
@@ -135,6 +137,7 @@ extern "C" int nbe_frame_stream_begin(nbe_engine* e, int every, int slots, int f
     FrameStream& fs = e->fs;
     fs.every = every; fs.first_frame = first_frame; fs.cb = cb; fs.user = user;
     fs.step_base = e->stats.steps;
+    fs.have_last = false;
     fs.stop = false; fs.copy_pending[0] = fs.copy_pending[1] = false;
     fs.queue.clear();
     int rc;
@@ -176,6 +179,8 @@ int frame_stream_before_step(nbe_engine* e)
     if (!fs.active) return NBE_OK;
     const uint64_t k = e->stats.steps - fs.step_base;
     if (k % (uint64_t)fs.every != 0 || e->n == 0) return NBE_OK;
+    if (fs.have_last && fs.last_k == k) return NBE_OK;    // this step's frame is out already (nbe_shard_prepare, then nbe_step)
+    fs.have_last = true; fs.last_k = k;
     int slot = -1;
     {
         std::unique_lock<std::mutex> lk(fs.mu);      // back-pressure: wait for a free buffer like a full channel
