@@ -323,14 +323,16 @@ def main():
             extra["default_scene_1002_tree_theta1"]["cpu_port_note"] = "C port of main.go:129-178 as written: serial build, 4 walk threads, reference COM update, last N mod 4 bodies unwalked"
 
     if not args.no_extra and world == 1:
-        # benchmark configuration 5 rehearsed on one GPU at 1/16 size: two galaxies on the reference's approach course
-        # (main.go:35-36), fp32 pair terms with fp64 sums and an fp64 integrator, softened, with the drift it is judged by
-        gp = physics.galaxy_pair(1 << 19, seed=1)
+        # benchmark configuration 5 at its full size on one GPU: two 8,388,608-body galaxies on the reference's approach
+        # course (main.go:35-36), fp32 pair terms with fp64 sums and an fp64 integrator, softened (eps = 1 m), 1000
+        # fused steps, with the drift it is judged by at 100 and 1000 steps
+        gp = physics.galaxy_pair(1 << 23, seed=1)
         e6 = Engine(mode="tree", precision="mixed", theta=0.5, eps=1.0, device=local)
         e6.upload(gp.pos, gp.vel, gp.mass)
         e6.set_stream(torch.cuda.current_stream().cuda_stream)
         ke0, pe0, p0 = e6.energy()
-        pscale = float(np.sum(gp.mass[:, None] * np.abs(gp.vel)))
+        pscale = float((gp.mass * np.linalg.norm(gp.vel, axis=1)).sum())
+        del gp
         drift = {}
         s6, done = 0.0, 0
         for upto in (100, 1000):
@@ -338,11 +340,42 @@ def main():
             done = upto
             ke1, pe1, p1 = e6.energy()
             drift[f"after_{upto}_steps"] = {"energy_drift_rel": abs((ke1 + pe1) - (ke0 + pe0)) / abs(ke0 + pe0),
-                                            "momentum_drift_rel": float(np.abs(p1 - p0).max()) / pscale}
-        extra["galaxy_pair_2x512k_bh_mixed_eps1"] = {
-            "ms_per_step": 1e3 * s6 / done, "steps": done, "drift": drift,
+                                            "momentum_drift_rel": float(np.linalg.norm(p1 - p0)) / pscale}
+        e6.step(1)                     # the energy left a built tree behind; time a step that sorts and builds itself
+        st6 = e6.step_timed()
+        extra["galaxy_pair_2x8M_bh_mixed_eps1"] = {
+            "bodies": 1 << 24, "ms_per_step": 1e3 * s6 / done, "steps_per_s": done / s6, "steps": done, "drift": drift,
+            "bodies_left": int(st6.n_alive), "ms_sort": st6.ms_sort, "ms_build": st6.ms_build, "ms_force": st6.ms_force,
+            "stated_bound": "|dE/E0| <= 2e-3 after 100 steps (asserted in tests/test_gpu_config5.py), <= 1e-2 after 1000; "
+                            "|dP|/sum m|v| <= 1e-5 after 100, <= 1e-3 after 1000",
             "note": "potential summed over the nodes the walk accepts (theta 0.5) at every checkpoint"}
         e6.close()
+        # the reference's own precision (fp64 throughout) and the mixed mode on the headline cloud: direct-sum force
+        # kernel and Barnes-Hut step, each with its fraction of the vector peak of its arithmetic
+        pd = physics.plummer(1 << 20, seed=1)
+        npairs = (1 << 20) * ((1 << 20) - 1)
+        for prec, key, peak in (("f64", "direct_f64_plummer_1M", 78.6), ("mixed", "direct_mixed_plummer_1M", FP32_VALU_PEAK_TFLOPS)):
+            ed = Engine(mode="direct", precision=prec, device=local)
+            ed.upload(pd.pos, pd.vel, pd.mass)
+            kd = ed.time_force_kernel(2)
+            extra[key] = {"force_kernel_ms": kd, "interactions_per_s": npairs / (kd * 1e-3),
+                          "vector_peak_tflops": peak,
+                          "force_kernel_frac_of_vector_peak": npairs * FLOP_PER_INTERACTION / (kd * 1e-3) / 1e12 / peak}
+            ed.close()
+        for prec, key, peak in (("f64", "bh_theta0.5_f64_plummer_1M", 78.6), ("mixed", "bh_theta0.5_mixed_plummer_1M", FP32_VALU_PEAK_TFLOPS)):
+            et = Engine(mode="tree", precision=prec, theta=0.5, device=local)
+            et.upload(pd.pos, pd.vel, pd.mass)
+            et.set_stream(torch.cuda.current_stream().cuda_stream)
+            st_ = timed_steps(lambda: et.step(1), sync, barrier, 2, 10)
+            stt = et.step_timed()
+            kt = et.time_force_kernel(3)
+            it_ = et.stats().interactions
+            extra[key] = {"ms_per_step": 1e3 * st_ / 10, "steps_per_s": 10 / st_, "ms_sort": stt.ms_sort, "ms_build": stt.ms_build,
+                          "ms_force": stt.ms_force, "interactions_per_step": int(it_), "force_kernel_ms": kt,
+                          "vector_peak_tflops": peak,
+                          "force_kernel_frac_of_vector_peak": it_ * FLOP_PER_INTERACTION / (kt * 1e-3) / 1e12 / peak}
+            et.close()
+        del pd
         # the 1M-body step with collisions on (radius 2 m, physics.go:20): search, queue, merge and update after the walk
         pl = physics.plummer(1 << 20, seed=1)
         e7 = Engine(mode="tree", precision="f32", theta=0.5, collisions=True, device=local)

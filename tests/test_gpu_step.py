@@ -134,6 +134,33 @@ def test_frame_stream_delivers_the_state_before_each_step(gpu, mode, precision):
         assert np.array_equal(xyzm[order, 3], m.astype(np.float32))
 
 
+@pytest.mark.parametrize("mode", ["direct", "tree"])
+def test_streamed_frames_equal_the_oracles_states(gpu, mode):
+    """Frame k of the stream is the state before step k*every (main.go:90-101): it must equal the CPU oracle's state
+    after k*every steps of main.go:104-178 (fp64 engine; frames carry fp32 x, y, z, mass, so positions agree to
+    fp32 rounding of the oracle's values plus the fp64 engine's 1e-10 trajectory tolerance)."""
+    b = physics.makebodies(598, seed=6)
+    every, nframes = 3, 4
+    got = {}
+    with Engine(mode=mode, precision="f64", theta=0.7) as e:
+        e.upload(b.pos, b.vel, b.mass, b.ids + 40)
+        e.frame_stream_begin(lambda f, xyzm, ids, radius: got.__setitem__(f, (xyzm, ids)), every=every, slots=3, first_frame=2)
+        e.step(every * (nframes - 1) + 1)
+        e.frame_stream_end()
+    assert sorted(got) == [2, 3, 4, 5]
+    kw = dict(mode="tree", com_mode="true", theta=0.7, drop_tail=False, max_depth=21) if mode == "tree" else dict(mode="direct")
+    for k in range(nframes):
+        pos, vel, alive, _ = O.step(b.mass, b.pos, b.vel, nsteps=k * every, **kw)
+        xyzm, ids = got[2 + k]
+        order = np.argsort(ids)
+        assert alive.all() and np.array_equal(ids[order], b.ids + 40)
+        assert np.array_equal(xyzm[order, 3], b.mass.astype(np.float32))
+        want = pos.astype(np.float32)
+        err = np.abs(xyzm[order, :3].astype(np.float64) - pos).max()
+        assert err <= 2e-7 * np.abs(pos).max(), err
+        assert (xyzm[order, :3] == want).mean() > 0.99          # all but a few last-bit roundings are identical
+
+
 def test_tree_potential_at_scale_matches_pair_sum(gpu):
     """Above 262,144 bodies nbe_energy takes the potential from the tree walk (same acceptance as the forces).
     On a 300k-body Plummer sphere it must agree with the exact pair sum of the direct engine to 2e-3, and the
