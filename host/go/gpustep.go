@@ -20,11 +20,12 @@ var (
 	gpuPrecision = flag.String("precision", "f64", "GPU arithmetic: f64, mixed (fp32 pair terms, fp64 sums and state) or f32")
 	gpuAsGo      = flag.Bool("asgo", false, "tree mode: the reference's running cell centres and unwalked last n mod 4 bodies")
 	gpuPerWave   = flag.Bool("perwave", false, "tree mode: the bodies of a wavefront open cells together (not the reference's interaction set)")
+	gpuCount     = flag.Int("gpus", 1, "GPUs driven by the one engine (needs -nocollision when above 1)")
 	gpuBlocking  = flag.Bool("blockingframes", false, "take frames with a blocking download instead of the side-stream ring")
 )
 
 func gpuOptionsFromFlags() gpuOptions {
-	opt := gpuOptions{precision: int(nbePrecF64), asGo: *gpuAsGo, perWave: *gpuPerWave}
+	opt := gpuOptions{precision: int(nbePrecF64), asGo: *gpuAsGo, perWave: *gpuPerWave, gpus: *gpuCount}
 	switch *gpuPrecision {
 	case "f32":
 		opt.precision = int(nbePrecF32)

@@ -4,7 +4,7 @@
 // reference's flags, its body type, its initial-condition generator and its frame loop:
 //   flags           main.go:17-24   -n -y -state -save -tree -norender -nocollision
 //                   (+ -seed -frames-dir -precision -asgo -perwave, and the reference's compile-time constants as
-//                   run-time values: -theta main.go:73, -dt main.go:28, -bound main.go:74-76, -eps softening, -G physics.go:132)
+//                   run-time values: -gpus N (one engine, N GPUs), -theta main.go:73, -dt main.go:28, -bound main.go:74-76, -eps softening, -G physics.go:132)
 //   makebodies      physics.go:16-73 with the two cores of main.go:35-36
 //   frame loop      main.go:80-190  (frames+1 iterations; a frame copy goes to the workers BEFORE each step)
 //   output workers  main.go:50-61   4 consumers behind a queue of capacity 32 (here fed by nbe_frame_stream_begin)
@@ -249,6 +249,7 @@ int main(int argc, char** argv)
     double dt = 60 * 60;                                     // main.go:28
     double eps = 0, bound = 65536, gconst = G;               // no softening; simbound main.go:74-76; physics.go:132
     int precision = NBE_PREC_F32;
+    int gpus = 1;                                            // the walk's fan-out (main.go:134-149) over this many GPUs
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
         if (a.rfind("--", 0) == 0) a = a.substr(1);
@@ -264,6 +265,7 @@ int main(int argc, char** argv)
         else if (const char* v = val("-seed")) seed = std::strtoull(v, nullptr, 10);
         else if (const char* v = val("-theta")) theta = std::atof(v);
         else if (const char* v = val("-dt")) dt = std::atof(v);
+        else if (const char* v = val("-gpus")) gpus = std::atoi(v);
         else if (const char* v = val("-eps")) eps = std::atof(v);
         else if (const char* v = val("-bound")) bound = std::atof(v);
         else if (const char* v = val("-G")) gconst = std::atof(v);
@@ -320,6 +322,7 @@ int main(int argc, char** argv)
     cfg.G = gconst;
     cfg.precision = precision;
     cfg.collisions = nocollision ? 0 : 1;                    // main.go:24
+    cfg.num_devices = gpus;                                  // > 1: devices 0 .. gpus-1 (needs -nocollision)
     // -asgo: the tree path with the Go program's own arithmetic (running cell centres tree.go:189-193, last
     // n mod 4 bodies unwalked main.go:134-148), for comparing a run with the reference number for number
     if (asgo && tree) cfg.reference_quirks = NBE_QUIRK_REF_COM | NBE_QUIRK_DROP_TAIL;

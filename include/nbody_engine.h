@@ -52,7 +52,20 @@ typedef struct {
                                tree.go:245-281 + main.go:151-167; direct sum: main.go:122-126; physics.go:153-162) */
     int reference_quirks;   /* tree mode: bit set of NBE_QUIRK_*; 0 = physically meant behaviour */
     int walk_criterion;     /* tree mode: NBE_WALK_PER_BODY (the reference's test, default) or NBE_WALK_PER_WAVE */
+    int num_devices;        /* 0 or 1: one GPU, `device`.  G > 1: the engine drives G GPUs from this process, see below */
+    const int *device_ids;  /* num_devices HIP device ordinals (copied by nbe_create); NULL = devices 0 .. G-1 */
 } nbe_config;
+
+/* Several GPUs behind one engine (num_devices = G > 1).  The reference's data-parallel strategy is a fan-out of
+ * contiguous body ranges over workers that share one read-only tree (main.go:134-149); here a worker is a GPU.  Every
+ * GPU holds all n bodies as sources and, in tree mode, sorts and builds the same tree; GPU g computes the forces on
+ * and integrates the g-th contiguous range of ceil(n/G) bodies (device order) and the engine copies every range to
+ * the other GPUs over the peer links (hipMemcpyPeerAsync on the receiving GPU's stream, ordered by events; no host
+ * synchronisation inside nbe_step).  Results are those of one GPU: bit for bit in tree mode, to the rounding of a
+ * differently split source range in the direct sum.  nbe_upload, nbe_step, nbe_download, nbe_accel, nbe_energy,
+ * nbe_stats, nbe_sync, nbe_tree_nodes, nbe_time_force_kernel and the frame stream work as with one GPU (reads come
+ * from the first GPU); collisions, nbe_step_timed, nbe_set_stream, nbe_device_state and the nbe_shard_* calls are
+ * refused with NBE_E_UNSUPPORTED.  The same ordinal may be listed more than once (several shards on one GPU). */
 
 /* Who decides whether a cell is opened (tree.go:216-217, edge / distance > theta).
  *   NBE_WALK_PER_BODY   every body for itself, as the reference's recursion does: each body receives exactly the
@@ -158,7 +171,9 @@ int nbe_energy(nbe_engine *e, double *kinetic, double *potential, double momentu
 /* ---- sharded stepping (one engine per GPU, every engine holds all n bodies as sources) ----
  * The reference's only data-parallel strategy is to give each of 4 goroutines a contiguous quarter of the
  * bodies against a shared read-only tree (main.go:134-149); a shard is that quarter.
- *   nbe_set_shard(first, count)   targets [first, first+count) in device order belong to this engine
+ *   nbe_set_shard(first, count)   targets [first, first+count) in device order belong to this engine (choose `first`
+ *                                 as a multiple of 64: tree mode then matches a one-engine run bit for bit in every
+ *                                 precision; otherwise NBE_PREC_MIXED differs in the last bits)
  *   nbe_shard_sort                optional, tree mode: the part of the sort that reads positions only (keys, radix
  *                                 passes), so that it can run while the velocities of the other engines still arrive
  *   nbe_shard_prepare             tree mode: sort by Morton key, reorder state, build the tree (replicated)

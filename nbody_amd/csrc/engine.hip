@@ -43,6 +43,13 @@ static int use_device(nbe_engine* e)
     return NBE_OK;
 }
 
+// Calls that a multi-GPU engine does not offer; the rest are served by the coordinator or by the first GPU's engine.
+#define NBE_NOT_MULTI(e, name)                                                                     \
+    do {                                                                                           \
+        if ((e)->multi) { nbe_set_error(name " is not available on an engine with num_devices > 1"); return NBE_E_UNSUPPORTED; } \
+    } while (0)
+#define NBE_FIRST(e) ((e) && (e)->multi ? multi_first(e) : (e))
+
 static int free_state(nbe_engine* e)
 {
     void** ptrs[] = {&e->posm[0], &e->posm[1], &e->vel[0], &e->vel[1], (void**)&e->mirror[0], (void**)&e->mirror[1],
@@ -72,15 +79,27 @@ extern "C" int nbe_create(const nbe_config* cfg, nbe_engine** out)
         return NBE_E_INVALID;
     }
     if (cfg->reference_quirks && cfg->mode != NBE_MODE_TREE) { nbe_set_error("reference_quirks apply to tree mode only"); return NBE_E_INVALID; }
+    if (cfg->num_devices < 0) { nbe_set_error("num_devices < 0"); return NBE_E_INVALID; }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
         nbe_set_error("no HIP device available (this library has no CPU path)");
         return NBE_E_DEVICE;
     }
-    if (cfg->device < 0 || cfg->device >= ndev) { nbe_set_error("device %d out of range (have %d)", cfg->device, ndev); return NBE_E_INVALID; }
+    if (cfg->num_devices > 1) {
+        for (int r = 0; r < cfg->num_devices; r++) {
+            const int d = cfg->device_ids ? cfg->device_ids[r] : r;
+            if (d < 0 || d >= ndev) { nbe_set_error("device %d out of range (have %d)", d, ndev); return NBE_E_INVALID; }
+        }
+        return multi_create(cfg, out);
+    }
+    const int one_device = (cfg->num_devices == 1 && cfg->device_ids) ? cfg->device_ids[0] : cfg->device;
+    if (one_device < 0 || one_device >= ndev) { nbe_set_error("device %d out of range (have %d)", one_device, ndev); return NBE_E_INVALID; }
     nbe_engine* e = new (std::nothrow) nbe_engine();
     if (!e) { nbe_set_error("out of host memory"); return NBE_E_NOMEM; }
     e->cfg = *cfg;
+    e->cfg.device = one_device;
+    e->cfg.num_devices = 1;
+    e->cfg.device_ids = nullptr;               // the caller's array is not retained
     e->state64 = cfg->precision != NBE_PREC_F32;
     e->force64 = cfg->precision == NBE_PREC_F64;
     e->elem = e->state64 ? 32 : 16;
@@ -111,6 +130,7 @@ extern "C" int nbe_create(const nbe_config* cfg, nbe_engine** out)
 extern "C" void nbe_destroy(nbe_engine* e)
 {
     if (!e) return;
+    if (e->multi) { multi_destroy(e); return; }
     (void)hipSetDevice(e->cfg.device);
     (void)frame_stream_stop(e);
     (void)hipStreamSynchronize(e->stream);
@@ -132,6 +152,7 @@ extern "C" void nbe_destroy(nbe_engine* e)
 extern "C" int nbe_set_stream(nbe_engine* e, void* hip_stream)
 {
     if (!e) { nbe_set_error("engine is NULL"); return NBE_E_INVALID; }
+    NBE_NOT_MULTI(e, "nbe_set_stream");
     NBE_TRY(use_device(e));
     NBE_HIP(hipStreamSynchronize(e->stream));
     e->stream = (hipStream_t)hip_stream;
@@ -148,6 +169,7 @@ extern "C" int nbe_upload(nbe_engine* e, size_t n, const double* pos, const doub
     if (e->cfg.mode == NBE_MODE_TREE && n > (1ull << 26)) { nbe_set_error("tree mode supports at most 2^26 bodies"); return NBE_E_UNSUPPORTED; }
     for (size_t i = 0; i < n; i++)
         if (!(mass[i] >= 0.0)) { nbe_set_error("mass[%zu] is negative or NaN", i); return NBE_E_INVALID; }
+    if (e->multi) return multi_upload(e, n, pos, vel, mass, id);
     int rc;
     try { rc = upload_state(e, n, pos, vel, mass, id); }
     catch (const std::bad_alloc&) { nbe_set_error("out of host memory"); rc = NBE_E_NOMEM; }
@@ -394,10 +416,11 @@ static int force_pass(nbe_engine* e, uint64_t t0, uint64_t t1, bool fused, bool 
 extern "C" int nbe_shard_prepare(nbe_engine* e)
 {
     if (!e) { nbe_set_error("engine is NULL"); return NBE_E_INVALID; }
+    NBE_NOT_MULTI(e, "nbe_shard_prepare");
     if (e->cfg.collisions) { nbe_set_error("sharded stepping does not support collisions; use nbe_step"); return NBE_E_UNSUPPORTED; }
     NBE_TRY(use_device(e));
     if (e->advance_pending) { nbe_set_error("nbe_shard_prepare before nbe_shard_commit"); return NBE_E_INVALID; }
-    if (!e->prepared) NBE_TRY(frame_stream_before_step(e));
+    NBE_TRY(frame_stream_before_step(e));       // sends this step's frame once, however often prepare is called
     if (e->cfg.mode == NBE_MODE_TREE && !e->prepared) NBE_TRY(tree_sort_and_build(e));
     e->prepared = true;
     return NBE_OK;
@@ -406,6 +429,7 @@ extern "C" int nbe_shard_prepare(nbe_engine* e)
 extern "C" int nbe_shard_sort(nbe_engine* e)
 {
     if (!e) { nbe_set_error("engine is NULL"); return NBE_E_INVALID; }
+    NBE_NOT_MULTI(e, "nbe_shard_sort");
     if (e->cfg.collisions) { nbe_set_error("sharded stepping does not support collisions; use nbe_step"); return NBE_E_UNSUPPORTED; }
     NBE_TRY(use_device(e));
     if (e->advance_pending) { nbe_set_error("nbe_shard_sort before nbe_shard_commit"); return NBE_E_INVALID; }
@@ -416,6 +440,7 @@ extern "C" int nbe_shard_sort(nbe_engine* e)
 extern "C" int nbe_shard_advance(nbe_engine* e)
 {
     if (!e) { nbe_set_error("engine is NULL"); return NBE_E_INVALID; }
+    NBE_NOT_MULTI(e, "nbe_shard_advance");
     if (e->cfg.collisions) { nbe_set_error("sharded stepping does not support collisions; use nbe_step"); return NBE_E_UNSUPPORTED; }
     NBE_TRY(use_device(e));
     if (!e->prepared) { nbe_set_error("nbe_shard_advance without nbe_shard_prepare"); return NBE_E_INVALID; }
@@ -444,6 +469,7 @@ __global__ __launch_bounds__(256) void refresh_mirror_kernel(const double4* __re
 extern "C" int nbe_shard_commit(nbe_engine* e)
 {
     if (!e) { nbe_set_error("engine is NULL"); return NBE_E_INVALID; }
+    NBE_NOT_MULTI(e, "nbe_shard_commit");
     if (!e->advance_pending) { nbe_set_error("nbe_shard_commit without nbe_shard_advance"); return NBE_E_INVALID; }
     NBE_TRY(use_device(e));
     if (e->cfg.precision == NBE_PREC_MIXED && e->shard_set && e->shard_count < e->n) {
@@ -463,6 +489,7 @@ extern "C" int nbe_shard_commit(nbe_engine* e)
 extern "C" int nbe_set_shard(nbe_engine* e, uint64_t first, uint64_t count)
 {
     if (!e) { nbe_set_error("engine is NULL"); return NBE_E_INVALID; }
+    NBE_NOT_MULTI(e, "nbe_set_shard");
     if (first > e->n || count > e->n - first) { nbe_set_error("shard [%llu, +%llu) outside 0..%zu", (unsigned long long)first, (unsigned long long)count, e->n); return NBE_E_INVALID; }
     if (e->advance_pending) { nbe_set_error("nbe_set_shard between advance and commit"); return NBE_E_INVALID; }
     e->shard_first = first;
@@ -474,6 +501,7 @@ extern "C" int nbe_set_shard(nbe_engine* e, uint64_t first, uint64_t count)
 extern "C" int nbe_device_state(nbe_engine* e, nbe_device_state_t* out)
 {
     if (!e || !out) { nbe_set_error("NULL argument"); return NBE_E_INVALID; }
+    NBE_NOT_MULTI(e, "nbe_device_state");
     out->pos_mass = e->posm[e->cur];
     out->vel = e->vel[e->cur];
     out->pos_mass_next = e->posm[e->cur ^ 1];
@@ -521,6 +549,7 @@ extern "C" int nbe_step(nbe_engine* e, int nsteps)
 {
     if (!e) { nbe_set_error("engine is NULL"); return NBE_E_INVALID; }
     if (nsteps < 0) { nbe_set_error("nsteps < 0"); return NBE_E_INVALID; }
+    if (e->multi) return multi_step(e, nsteps);
     NBE_TRY(use_device(e));
     if (e->advance_pending) { nbe_set_error("nbe_step between nbe_shard_advance and nbe_shard_commit"); return NBE_E_INVALID; }
     if (e->shard_set && (e->shard_first != 0 || e->shard_count != e->n)) {
@@ -550,6 +579,7 @@ static int fetch_interactions(nbe_engine* e)
 extern "C" int nbe_step_timed(nbe_engine* e, nbe_stats_t* stats)
 {
     if (!e) { nbe_set_error("engine is NULL"); return NBE_E_INVALID; }
+    NBE_NOT_MULTI(e, "nbe_step_timed");
     NBE_TRY(use_device(e));
     if (e->n == 0) { if (stats) *stats = e->stats; return NBE_OK; }
     if (e->advance_pending) { nbe_set_error("nbe_step_timed between nbe_shard_advance and nbe_shard_commit"); return NBE_E_INVALID; }
@@ -573,6 +603,7 @@ extern "C" int nbe_step_timed(nbe_engine* e, nbe_stats_t* stats)
 extern "C" int nbe_sync(nbe_engine* e)
 {
     if (!e) { nbe_set_error("engine is NULL"); return NBE_E_INVALID; }
+    if (e->multi) return multi_sync(e);
     NBE_TRY(use_device(e));
     NBE_HIP(hipStreamSynchronize(e->stream));
     return NBE_OK;
@@ -581,6 +612,7 @@ extern "C" int nbe_sync(nbe_engine* e)
 extern "C" int nbe_stats(nbe_engine* e, nbe_stats_t* stats)
 {
     if (!e || !stats) { nbe_set_error("NULL argument"); return NBE_E_INVALID; }
+    e = NBE_FIRST(e);
     NBE_TRY(use_device(e));
     NBE_TRY(fetch_interactions(e));
     size_t na;
@@ -626,6 +658,7 @@ static int accel_impl(nbe_engine* e, double* acc_xyz, uint8_t* alive_out)
 extern "C" int nbe_energy(nbe_engine* e, double* kinetic, double* potential, double momentum[3])
 {
     if (!e) { nbe_set_error("engine is NULL"); return NBE_E_INVALID; }
+    e = NBE_FIRST(e);
     NBE_TRY(use_device(e));
     if (e->advance_pending) { nbe_set_error("nbe_energy between nbe_shard_advance and nbe_shard_commit"); return NBE_E_INVALID; }
     return energy_compute(e, kinetic, potential, momentum);
@@ -634,6 +667,7 @@ extern "C" int nbe_energy(nbe_engine* e, double* kinetic, double* potential, dou
 extern "C" int nbe_time_force_kernel(nbe_engine* e, int reps, float* ms_per_launch)
 {
     if (!e || !ms_per_launch || reps <= 0) { nbe_set_error("bad argument"); return NBE_E_INVALID; }
+    e = NBE_FIRST(e);          // several GPUs: the first one's range
     NBE_TRY(use_device(e));
     if (e->advance_pending) { nbe_set_error("nbe_time_force_kernel inside a sharded step"); return NBE_E_INVALID; }
     *ms_per_launch = 0;
@@ -694,8 +728,8 @@ static int tree_nodes_impl(nbe_engine* e, double* out, size_t cap, size_t* count
     try { return (call); }                                                               \
     catch (const std::bad_alloc&) { nbe_set_error("out of host memory"); return NBE_E_NOMEM; }
 
-extern "C" int nbe_download(nbe_engine* e, double* pos, double* vel, double* mass, uint64_t* id, size_t* n_alive_out) { NBE_GUARDED(download_impl(e, pos, vel, mass, id, n_alive_out)) }
-extern "C" int nbe_set_radius(nbe_engine* e, const double* radius) { NBE_GUARDED(set_radius_impl(e, radius)) }
-extern "C" int nbe_get_radius(nbe_engine* e, double* radius, size_t* n_alive_out) { NBE_GUARDED(get_radius_impl(e, radius, n_alive_out)) }
-extern "C" int nbe_accel(nbe_engine* e, double* acc_xyz, uint8_t* alive_out) { NBE_GUARDED(accel_impl(e, acc_xyz, alive_out)) }
-extern "C" int nbe_tree_nodes(nbe_engine* e, double* out, size_t cap, size_t* count) { NBE_GUARDED(tree_nodes_impl(e, out, cap, count)) }
+extern "C" int nbe_download(nbe_engine* e, double* pos, double* vel, double* mass, uint64_t* id, size_t* n_alive_out) { NBE_GUARDED(download_impl(NBE_FIRST(e), pos, vel, mass, id, n_alive_out)) }
+extern "C" int nbe_set_radius(nbe_engine* e, const double* radius) { NBE_GUARDED(set_radius_impl(NBE_FIRST(e), radius)) }
+extern "C" int nbe_get_radius(nbe_engine* e, double* radius, size_t* n_alive_out) { NBE_GUARDED(get_radius_impl(NBE_FIRST(e), radius, n_alive_out)) }
+extern "C" int nbe_accel(nbe_engine* e, double* acc_xyz, uint8_t* alive_out) { NBE_GUARDED(accel_impl(NBE_FIRST(e), acc_xyz, alive_out)) }
+extern "C" int nbe_tree_nodes(nbe_engine* e, double* out, size_t cap, size_t* count) { NBE_GUARDED(tree_nodes_impl(NBE_FIRST(e), out, cap, count)) }

@@ -138,8 +138,11 @@ struct FrameStream {
     std::vector<uint64_t> ids_scratch;
 };
 
+struct MultiState;
+
 struct nbe_engine {
     nbe_config cfg{};
+    MultiState* multi = nullptr;    // num_devices > 1: this object only coordinates one engine per GPU (multi.hip)
     size_t n = 0;
     double equal_mass = 0.0;        // direct sum without collisions: the common mass if every body has the same, else 0
     bool state64 = false;           // fp64 state (MIXED and F64)
@@ -182,6 +185,13 @@ struct nbe_engine {
 };
 
 // ---- functions implemented across the translation units ----------------------------------------------
+// multi.hip: one engine per GPU behind one handle
+int multi_create(const nbe_config* cfg, nbe_engine** out);
+void multi_destroy(nbe_engine* e);
+int multi_upload(nbe_engine* e, size_t n, const double* pos, const double* vel, const double* mass, const uint64_t* id);
+int multi_step(nbe_engine* e, int nsteps);
+int multi_sync(nbe_engine* e);
+nbe_engine* multi_first(nbe_engine* e);          // the engine of the first GPU (reads are served from it)
 // direct.hip
 int direct_forces(nbe_engine* e, int src_buf, uint64_t t0, uint64_t t1, bool fused, int dst_buf);
 // tree_build.hip

@@ -34,7 +34,8 @@ class Config(C.Structure):
     _fields_ = [("mode", C.c_int), ("precision", C.c_int), ("G", C.c_double), ("theta", C.c_double),
                 ("dt", C.c_double), ("eps", C.c_double), ("bound_center", C.c_double * 3),
                 ("bound_width", C.c_double), ("device", C.c_int), ("collisions", C.c_int),
-                ("reference_quirks", C.c_int), ("walk_criterion", C.c_int)]
+                ("reference_quirks", C.c_int), ("walk_criterion", C.c_int), ("num_devices", C.c_int),
+                ("device_ids", C.POINTER(C.c_int))]
 
 
 class Stats(C.Structure):
@@ -118,7 +119,10 @@ class Engine:
 
     def __init__(self, mode="direct", precision="f32", theta=None, dt=None, eps=None, G=None,
                  bound_center=None, bound_width=None, device=0, collisions=False, ref_com=False,
-                 drop_tail=False, per_wave=False):
+                 drop_tail=False, per_wave=False, devices=None):
+        """devices: a list of HIP device ordinals; with more than one the engine itself drives all of them from this
+        process (targets split into contiguous ranges, ranges copied between the GPUs every step); the same ordinal
+        may appear more than once."""
         self._lib = load_library()
         cfg = Config()
         self._check(self._lib.nbe_default_config(C.byref(cfg)))
@@ -137,6 +141,10 @@ class Engine:
         if bound_width is not None:
             cfg.bound_width = float(bound_width)
         cfg.device = int(device)
+        if devices is not None:
+            ids = (C.c_int * len(devices))(*[int(d) for d in devices])
+            cfg.num_devices = len(devices)
+            cfg.device_ids = C.cast(ids, C.POINTER(C.c_int))
         cfg.collisions = int(bool(collisions))      # False = the reference's -nocollision run (main.go:24)
         # the reference's running "centre of mass" (tree.go:189-193) and its unwalked last n mod 4 bodies
         # (main.go:134-148), for number-for-number comparisons with the Go program
@@ -147,6 +155,7 @@ class Engine:
         self.cfg = cfg
         self._h = C.c_void_p()
         self._check(self._lib.nbe_create(C.byref(cfg), C.byref(self._h)))
+        cfg.device_ids = None                      # nbe_create copied the list
         self.n = 0
 
     def _check(self, rc):

@@ -18,9 +18,13 @@ except Exception:  # pragma: no cover - torch is part of the image
     dist = None
 
 
-def shard_range(n, rank, world):
-    """Contiguous range of ceil(n/world) targets per rank (the last ranks may get fewer or none)."""
+def shard_range(n, rank, world, align=256):
+    """Contiguous range of ceil(n/world) targets per rank, rounded up to a multiple of 256 (the last ranks may get
+    fewer or none).  Ranges that start at multiples of 256 give the wavefronts of the tree walk the same 64 bodies as
+    a one-GPU run, which mixed precision needs to round as one GPU does (its fp32 partial sums join the fp64 totals
+    every 64 node visits of the wavefront)."""
     per = (n + world - 1) // world
+    per = (per + align - 1) // align * align
     first = min(rank * per, n)
     return first, min(per, n - first), per
 
@@ -79,15 +83,17 @@ class EngineShard:
 class ShardedStepper:
     """Drives one rank's shard.  `shard` is an EngineShard (or anything with the same methods)."""
 
-    def __init__(self, shard, rank=None, world=None, group=None, always_gather=False):
-        """always_gather: run the collectives even with a single rank (exercises the RCCL path on one GPU)."""
+    def __init__(self, shard, rank=None, world=None, group=None, always_gather=False, align=256):
+        """always_gather: run the collectives even with a single rank (exercises the RCCL path on one GPU).
+        align: target ranges start at multiples of this many bodies (see shard_range)."""
+        self.align = align
         self.always_gather = always_gather
         self.shard = shard
         self.group = group
         self.rank = dist.get_rank(group) if rank is None else rank
         self.world = dist.get_world_size(group) if world is None else world
         self.n = shard.n
-        self.first, self.count, self.per = shard_range(self.n, self.rank, self.world)
+        self.first, self.count, self.per = shard_range(self.n, self.rank, self.world, align)
         shard.set_shard(self.first, self.count)
         self.even = self.per * self.world == self.n
         self.backend = dist.get_backend(group) if (self.world > 1 or always_gather) else None
@@ -111,7 +117,7 @@ class ShardedStepper:
             mine[:self.count] = work[self.first:self.first + self.count]
             dist.all_gather_into_tensor(padded, mine, group=self.group)
             for r in range(self.world):
-                f, c, _ = shard_range(self.n, r, self.world)
+                f, c, _ = shard_range(self.n, r, self.world, self.align)
                 if c:
                     work[f:f + c] = padded[r * self.per:r * self.per + c]
         if host_stage:

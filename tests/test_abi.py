@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_struct_layouts_match_header_sizes():
-    assert C.sizeof(E.Config) == 2 * 4 + 4 * 8 + 3 * 8 + 8 + 4 * 4
+    assert C.sizeof(E.Config) == 2 * 4 + 4 * 8 + 3 * 8 + 8 + 4 * 4 + 4 + 4 + 8      # ... num_devices, padding, device_ids
     assert C.sizeof(E.Stats) == 8 * 8 + 4 * 4
     assert C.sizeof(E.DeviceState) == 4 * 8 + 8 + 4 + 4
 
@@ -79,12 +79,12 @@ def test_no_cpu_fallback_without_a_gpu():
     assert "no HIP device" in str(ei.value) or "device" in str(ei.value)
 
 
-def _build_c_client():
+def _build_c_client(name="abi_smoke"):
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    exe = os.path.join(root, "tests", "c", "abi_smoke")
+    exe = os.path.join(root, "tests", "c", name)
     subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(root, "include"),
-                           "-o", exe, os.path.join(root, "tests", "c", "abi_smoke.c"), "-L" + os.path.join(root, "nbody_amd"),
+                           "-o", exe, os.path.join(root, "tests", "c", name + ".c"), "-L" + os.path.join(root, "nbody_amd"),
                            "-lnbody_engine", "-Wl,-rpath," + os.path.join(root, "nbody_amd")])
     return exe
 
@@ -105,3 +105,16 @@ def test_c_client_steps_a_scene(gpu):
     import subprocess
     r = subprocess.run([_build_c_client(), "run"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=120)
     assert r.returncode == 0 and b"abi smoke ok" in r.stdout, r.stdout.decode()
+
+
+def test_multi_shard_c_client_builds():
+    _build_c_client("abi_multi")
+
+
+@pytest.mark.gpu
+def test_c_client_with_several_shards_equals_one_shard(gpu):
+    """One engine handle with num_devices = 2, 3, 4 (all on device 0) against one shard: tree mode bit for bit in all
+    three precisions, direct sum to rounding; 5,003 bodies (uneven ranges), one of which leaves the bound."""
+    import subprocess
+    r = subprocess.run([_build_c_client("abi_multi")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    assert r.returncode == 0 and b"abi multi ok" in r.stdout, r.stdout.decode()

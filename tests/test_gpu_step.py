@@ -83,7 +83,7 @@ def test_call_order_errors(gpu):
 
 
 @pytest.mark.parametrize("mode,precision,n", [("tree", "f32", 4096), ("tree", "f64", 1001), ("direct", "f32", 4096),
-                                              ("direct", "mixed", 999)])
+                                              ("direct", "mixed", 999), ("tree", "mixed", 3001)])
 def test_two_ranks_on_one_gpu_match_single_engine(gpu, tmp_path, mode, precision, n):
     """world_size 2 over gloo, both ranks on cuda:0, real engines: each advances half the targets and the
     halves are all-gathered; the result must equal one engine stepping everything.  The tree walk gives each
@@ -293,6 +293,42 @@ def test_sort_running_ahead_does_not_change_who_is_alive(gpu, n):
         assert len(want[0]) == n - 1 and 17 not in want[3]
         for a, w in zip(got, want):
             assert np.array_equal(a, w)
+
+
+@pytest.mark.parametrize("mode,precision,extra", [("tree", "f32", {}), ("tree", "mixed", {}), ("tree", "f32", {"per_wave": True}),
+                                                  ("tree", "f64", {"ref_com": True, "drop_tail": True}), ("direct", "f32", {})])
+def test_engine_driving_several_shards_itself(gpu, mode, precision, extra):
+    """Engine(devices=[0, 0, 0]): one handle, three shards on this GPU, ranges exchanged by the engine's own peer
+    copies (no torch.distributed).  Tree mode equals a one-shard engine bit for bit, with frames, energies and
+    accelerations served by the first shard; the direct sum agrees to the rounding of its source-range split."""
+    b = physics.plummer(20001, seed=8, a=2e3)
+    frames = []
+    with Engine(mode=mode, precision=precision, theta=0.6, **extra) as one:
+        one.upload(b.pos, b.vel, b.mass)
+        acc1, _ = one.accel()
+        one.step(5)
+        want = one.download()
+        en1 = one.energy()
+    with Engine(mode=mode, precision=precision, theta=0.6, devices=[0, 0, 0], **extra) as e:
+        e.upload(b.pos, b.vel, b.mass)
+        acc3, _ = e.accel()
+        e.frame_stream_begin(lambda f, xyzm, ids, radius: frames.append((f, xyzm, ids)), every=2, slots=2)
+        e.step(5)
+        e.frame_stream_end()
+        got = e.download()
+        en3 = e.energy()
+        assert e.stats().steps == 5
+        with pytest.raises(EngineError, match="num_devices"):
+            e.step_timed()
+    assert [f for f, _, _ in frames] == [0, 1, 2] and all(len(ids) == len(b) for _, _, ids in frames)
+    if mode == "tree":
+        assert np.array_equal(acc1, acc3)
+        for a, w in zip(got, want):
+            assert np.array_equal(a, w)
+        assert abs(en1[0] - en3[0]) <= 1e-12 * en1[0] and abs(en1[1] - en3[1]) <= 1e-12 * abs(en1[1])
+    else:
+        assert np.abs(got[0] - want[0]).max() <= 1e-6 * np.abs(want[0]).max()
+        assert np.abs(got[1] - want[1]).max() <= 1e-5 * np.abs(want[1]).max()
 
 
 def test_two_engines_in_one_process_do_not_share_state(gpu):

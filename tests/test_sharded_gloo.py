@@ -52,8 +52,14 @@ def test_shard_ranges_cover_everything_once():
         for world in (1, 2, 3, 8):
             seen = []
             for r in range(world):
-                f, c, per = shard_range(n, r, world)
+                f, c, per = shard_range(n, r, world, align=1)
                 assert per == (n + world - 1) // world and 0 <= c <= per
+                seen += list(range(f, f + c))
+            assert seen == list(range(n))
+            seen = []
+            for r in range(world):                      # default: ranges start at multiples of 256 bodies
+                f, c, per = shard_range(n, r, world)
+                assert per % 256 == 0 and f % 256 == 0 or c == 0
                 seen += list(range(f, f + c))
             assert seen == list(range(n))
 
