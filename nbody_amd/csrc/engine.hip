@@ -139,7 +139,7 @@ extern "C" void nbe_destroy(nbe_engine* e)
     (void)direct_collide_free(e);
     TreeWork& w = e->tw;
     void* ptrs[] = {w.keys[0], w.keys[1], w.sidx[0], w.sidx[1], w.block_hist, w.scan_tmp, w.bt_first, w.bt_last, w.bt_parent,
-                    w.bt_level, w.lvlmask, w.cellcnt, w.nodes, w.node_level, w.node_sum, w.counters, w.d_interactions,
+                    w.bt_level, w.bt_cell, w.lvlmask, w.cellcnt, w.nodes, w.node_level, w.node_sum, w.counters, w.d_interactions,
                     w.prefix, w.prefix_tiles, e->d_energy};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);

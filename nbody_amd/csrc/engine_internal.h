@@ -65,6 +65,7 @@ struct TreeWork {
     int* bt_last = nullptr;
     int* bt_parent = nullptr;
     uint8_t* bt_level = nullptr;
+    uint8_t* bt_cell = nullptr;     // per binary node: 1 iff it is an octree branching cell (depth differs from its parent's)
     uint32_t* lvlmask = nullptr;    // per sorted leaf: bit L set iff a branching cell of depth L starts here
     uint32_t* cellcnt = nullptr;    // exclusive scan of popcount(lvlmask), n+1 entries
     void* nodes = nullptr;          // NodeF[2n] or NodeD[2n]

@@ -452,9 +452,12 @@ __global__ __launch_bounds__(256) void permute_kernel(const uint32_t* __restrict
                                                       const float4* __restrict__ mirror_in, const double* __restrict__ radius_in,
                                                       S4* __restrict__ pos_out, S4* __restrict__ vel_out,
                                                       uint32_t* __restrict__ orig_out, float4* __restrict__ mirror_out,
-                                                      double* __restrict__ radius_out, int* __restrict__ counters)
+                                                      double* __restrict__ radius_out, int* __restrict__ counters,
+                                                      uint32_t* __restrict__ lvlmask)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
+    // the cell marks of the coming build start from zero (n + 1 entries; radix_tree_kernel sets bits with atomics)
+    if (i <= n) lvlmask[i] = 0;
     if (i == 0) {
         // The sort left its live count aside (it may have run ahead, while the state was still in the previous
         // order and counters[0..3] still described that order); from here on the state is in the new order.
@@ -471,51 +474,85 @@ __global__ __launch_bounds__(256) void permute_kernel(const uint32_t* __restrict
 }
 
 // ---- binary radix tree over the sorted keys ----------------------------------------------------------------
+// Also decides which binary nodes are octree cells: a node is a branching cell iff its depth (common prefix / 3)
+// differs from its parent's.  The parent decides that for its two children, whose depths follow from the keys at the
+// ends of their ranges, writes the verdict to bt_cell[child] and sets bit `depth` in lvlmask[first leaf of child]
+// (lvlmask was zeroed by permute_kernel); the root is always a cell.
+// The searches of a node with a short range (most nodes) probe keys near its own index: the workgroup keeps the keys
+// of its 256 nodes and RT_HALO neighbours on either side in LDS and only longer probes go to memory.
+#define RT_HALO 128
+struct KeyWindow {
+    const uint64_t* __restrict__ keys;
+    const uint64_t* lds;
+    int lo, hi, na;                       // lds[j - lo] == keys[j] for lo <= j < hi
+    __device__ __forceinline__ uint64_t at(int j) const { return (j >= lo && j < hi) ? lds[j - lo] : keys[j]; }
+    // delta(i, j) as key_delta: common prefix length, index as tie-break for equal keys, -1 outside [0, na)
+    __device__ __forceinline__ int delta(int i, uint64_t ki, int j) const
+    {
+        if (j < 0 || j >= na) return -1;
+        const uint64_t kj = at(j);
+        if (ki != kj) return __clzll((long long)(ki ^ kj)) - 1;
+        return 63 + __clz(i ^ j);
+    }
+};
+
 __global__ __launch_bounds__(256) void radix_tree_kernel(const uint64_t* __restrict__ keys, const int* __restrict__ counters,
                                                          int* __restrict__ bt_first, int* __restrict__ bt_last,
-                                                         int* __restrict__ bt_parent, uint8_t* __restrict__ bt_level)
+                                                         int* __restrict__ bt_parent, uint8_t* __restrict__ bt_level,
+                                                         uint8_t* __restrict__ bt_cell, uint32_t* __restrict__ lvlmask)
 {
+    __shared__ uint64_t skeys[256 + 2 * RT_HALO];
     const int na = counters[0];
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int base = blockIdx.x * 256;
+    if (base >= na - 1) return;
+    KeyWindow kw;
+    kw.keys = keys; kw.lds = skeys; kw.na = na;
+    kw.lo = base - RT_HALO < 0 ? 0 : base - RT_HALO;
+    kw.hi = base + 256 + RT_HALO > na ? na : base + 256 + RT_HALO;
+    for (int j = kw.lo + threadIdx.x; j < kw.hi; j += 256) skeys[j - kw.lo] = keys[j];
+    __syncthreads();
+    const int i = base + threadIdx.x;
     if (i >= na - 1) return;
-    const uint64_t ki = keys[i];
-    const int dl = key_delta(keys, na, i, ki, i - 1), dr = key_delta(keys, na, i, ki, i + 1);
+    const uint64_t ki = kw.at(i);
+    const int dl = kw.delta(i, ki, i - 1), dr = kw.delta(i, ki, i + 1);
     const int d = dr > dl ? 1 : -1;
     const int dmin = dr > dl ? dl : dr;
     int lmax = 2;
-    while (key_delta(keys, na, i, ki, i + lmax * d) > dmin) lmax <<= 1;
+    while (kw.delta(i, ki, i + lmax * d) > dmin) lmax <<= 1;
     int l = 0;
     for (int t = lmax >> 1; t >= 1; t >>= 1)
-        if (key_delta(keys, na, i, ki, i + (l + t) * d) > dmin) l += t;
+        if (kw.delta(i, ki, i + (l + t) * d) > dmin) l += t;
     const int j = i + l * d;
-    const int dnode = key_delta(keys, na, i, ki, j);
+    const int dnode = kw.delta(i, ki, j);
     int s = 0;
     int t = l;
     do {
         t = (t + 1) >> 1;
-        if (key_delta(keys, na, i, ki, i + (s + t) * d) > dnode) s += t;
+        if (kw.delta(i, ki, i + (s + t) * d) > dnode) s += t;
     } while (t > 1);
     const int gamma = i + s * d + (d < 0 ? -1 : 0);
     const int lo = i < j ? i : j, hi = i < j ? j : i;
     bt_first[i] = lo;
     bt_last[i] = hi;
-    bt_level[i] = (uint8_t)delta_level(dnode);
-    if (i == 0) bt_parent[0] = -1;
-    if (lo != gamma) bt_parent[gamma] = i;           // left child is internal node gamma
-    if (hi != gamma + 1) bt_parent[gamma + 1] = i;   // right child is internal node gamma+1
-}
-
-// A binary node is an octree branching cell iff its depth differs from its parent's.
-__global__ __launch_bounds__(256) void mark_cells_kernel(const int* __restrict__ counters, const int* __restrict__ bt_first,
-                                                         const int* __restrict__ bt_parent, const uint8_t* __restrict__ bt_level,
-                                                         uint32_t* __restrict__ lvlmask)
-{
-    const int na = counters[0];
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= na - 1) return;
-    const int par = bt_parent[i];
-    const int lvl = bt_level[i];
-    if (par < 0 || bt_level[par] != lvl) atomicOr(&lvlmask[bt_first[i]], 1u << lvl);
+    const int lvl = delta_level(dnode);
+    bt_level[i] = (uint8_t)lvl;
+    if (i == 0) {
+        bt_parent[0] = -1;
+        bt_cell[0] = 1;
+        atomicOr(&lvlmask[0], 1u << lvl);
+    }
+    if (lo != gamma) {                               // left child is internal node gamma, covering [lo, gamma]
+        bt_parent[gamma] = i;
+        const int cl = delta_level(kw.delta(lo, kw.at(lo), gamma));
+        bt_cell[gamma] = cl != lvl;
+        if (cl != lvl) atomicOr(&lvlmask[lo], 1u << cl);
+    }
+    if (hi != gamma + 1) {                           // right child is internal node gamma+1, covering [gamma+1, hi]
+        bt_parent[gamma + 1] = i;
+        const int cl = delta_level(kw.delta(gamma + 1, kw.at(gamma + 1), hi));
+        bt_cell[gamma + 1] = cl != lvl;
+        if (cl != lvl) atomicOr(&lvlmask[gamma + 1], 1u << cl);
+    }
 }
 
 // fp32 nodes store (edge / theta)^2 for the walk's one-compare opening test; theta = 0 ("always open") maps to
@@ -648,17 +685,32 @@ __global__ __launch_bounds__(256) void psum_apply_kernel(const R4* __restrict__ 
                                                          D4* __restrict__ prefix)
 {
     __shared__ PsumTile<R4> tile;
+    // A thread owns eight consecutive 32-byte prefix records; stored straight from registers, the lanes of a wave
+    // write 256 bytes apart and the memory system sees partial lines (84 MB written for a 33.5 MB array at 1M
+    // bodies).  The records go through LDS instead, four per thread at a time (rows of four padded by one against
+    // bank conflicts), and leave with consecutive lanes on consecutive records.
+    __shared__ D4 stage[256 * 5];
     tile.load(posm, blockIdx.x * PSUM_TILE, n);
-    const int base = blockIdx.x * PSUM_TILE + threadIdx.x * 8;
     D4 v[8], s{0, 0, 0, 0};
 #pragma unroll
     for (int k = 0; k < 8; k++) { v[k] = tile.moments(k); s = d4_add(s, v[k]); }
     D4 tot;
     D4 off = d4_add(tile_offsets[blockIdx.x], block_excl_scan_d4(s, &tot));
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
-        if (base + k <= n) prefix[base + k] = off;
-        off = d4_add(off, v[k]);
+    for (int half = 0; half < 2; half++) {
+        if (half) __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            stage[threadIdx.x * 5 + k] = off;
+            off = d4_add(off, v[half * 4 + k]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int r = q * 256 + threadIdx.x, owner = r >> 2, kk = r & 3;
+            const int i = blockIdx.x * PSUM_TILE + owner * 8 + half * 4 + kk;
+            if (i <= n) prefix[i] = stage[owner * 5 + kk];
+        }
     }
 }
 
@@ -691,7 +743,7 @@ __global__ __launch_bounds__(256) void psum_single_kernel(const R4* __restrict__
 template <typename R4, typename NodeT, bool PREFIX>
 __global__ __launch_bounds__(256) void emit_nodes_kernel(int n, int* __restrict__ counters, const R4* __restrict__ posm,
                                                          const int* __restrict__ bt_first, const int* __restrict__ bt_last,
-                                                         const int* __restrict__ bt_parent, const uint8_t* __restrict__ bt_level,
+                                                         const uint8_t* __restrict__ bt_cell, const uint8_t* __restrict__ bt_level,
                                                          const uint32_t* __restrict__ lvlmask, const uint32_t* __restrict__ cellcnt,
                                                          double bound_width, double theta, NodeT* __restrict__ nodes,
                                                          uint8_t* __restrict__ node_level, double* __restrict__ node_sum,
@@ -731,9 +783,8 @@ __global__ __launch_bounds__(256) void emit_nodes_kernel(int n, int* __restrict_
     }
     const int i = t - n;
     if (i >= na - 1) return;
-    const int par = bt_parent[i];
+    if (!bt_cell[i]) return;
     const int lvl = bt_level[i];
-    if (!(par < 0 || bt_level[par] != lvl)) return;
     const int a = bt_first[i], b = bt_last[i];
     const int pos = a + (int)cellcnt[a] + __popc(lvlmask[a] & ((1u << lvl) - 1u));
     NodeT nd;
@@ -887,7 +938,7 @@ template <typename R4, typename NodeT>
 __global__ __launch_bounds__(256) void ref_com_kernel(int n, const int* __restrict__ counters, const R4* __restrict__ posm,
                                                       const uint32_t* __restrict__ orig, const uint32_t* __restrict__ inv,
                                                       const int* __restrict__ bt_first, const int* __restrict__ bt_last,
-                                                      const int* __restrict__ bt_parent, const uint8_t* __restrict__ bt_level,
+                                                      const uint8_t* __restrict__ bt_cell, const uint8_t* __restrict__ bt_level,
                                                       const uint32_t* __restrict__ lvlmask, const uint32_t* __restrict__ cellcnt,
                                                       NodeT* __restrict__ nodes)
 {
@@ -895,9 +946,8 @@ __global__ __launch_bounds__(256) void ref_com_kernel(int n, const int* __restri
     const int i = (int)((blockIdx.x * 256u + threadIdx.x) >> 6);
     const int lane = threadIdx.x & 63;
     if (i >= na - 1) return;
-    const int par = bt_parent[i];
+    if (!bt_cell[i]) return;
     const int lvl = bt_level[i];
-    if (!(par < 0 || bt_level[par] != lvl)) return;
     const int a = bt_first[i], b = bt_last[i];
     const int c = b - a + 1;
     const int pos = a + (int)cellcnt[a] + __popc(lvlmask[a] & ((1u << lvl) - 1u));
@@ -964,7 +1014,7 @@ int tree_workspace_reserve(nbe_engine* e)
     if (w.cap >= n && w.cap > 0) return NBE_OK;
     void** ptrs[] = {(void**)&w.keys[0], (void**)&w.keys[1], (void**)&w.sidx[0], (void**)&w.sidx[1], (void**)&w.block_hist,
                      (void**)&w.scan_tmp, (void**)&w.bt_first, (void**)&w.bt_last, (void**)&w.bt_parent, (void**)&w.bt_level,
-                     (void**)&w.lvlmask, (void**)&w.cellcnt, (void**)&w.nodes, (void**)&w.node_level, (void**)&w.node_sum,
+                     (void**)&w.bt_cell, (void**)&w.lvlmask, (void**)&w.cellcnt, (void**)&w.nodes, (void**)&w.node_level, (void**)&w.node_sum,
                      (void**)&w.counters, (void**)&w.d_interactions, (void**)&w.prefix, (void**)&w.prefix_tiles};
     for (void** p : ptrs) NBE_TRY(free_ptr(p));
     const size_t cap = n > 0 ? n : 1;
@@ -984,6 +1034,7 @@ int tree_workspace_reserve(nbe_engine* e)
     NBE_HIP(hipMalloc((void**)&w.bt_last, cap * 4));
     NBE_HIP(hipMalloc((void**)&w.bt_parent, cap * 4));
     NBE_HIP(hipMalloc((void**)&w.bt_level, cap));
+    NBE_HIP(hipMalloc((void**)&w.bt_cell, cap));
     NBE_HIP(hipMalloc((void**)&w.lvlmask, (cap + 1) * 4));
     NBE_HIP(hipMalloc((void**)&w.cellcnt, (cap + 1) * 4));
     NBE_HIP(hipMalloc((void**)&w.nodes, (2 * cap + 2) * node_bytes));   // the walk prefetches one record past the end
@@ -1057,10 +1108,10 @@ static int sort_and_build_t(nbe_engine* e)
     if (!e->keys_sorted) NBE_TRY(sort_keys_t<R4>(e));        // unless tree_sort_keys ran ahead of this call
     e->keys_sorted = false;
     NBE_TRY(frame_stream_guard_write(e, nxt));
-    hipLaunchKernelGGL((permute_kernel<S4>), dim3(nb), dim3(256), 0, e->stream, w.sidx[0], n, (const S4*)e->posm[cur],
+    hipLaunchKernelGGL((permute_kernel<S4>), dim3(cdiv((size_t)n + 1, 256)), dim3(256), 0, e->stream, w.sidx[0], n, (const S4*)e->posm[cur],
                        (const S4*)e->vel[cur], e->orig[e->orig_cur], mixed ? e->mirror[cur] : (const float4*)nullptr,
                        (const double*)e->radius[cur], (S4*)e->posm[nxt], (S4*)e->vel[nxt], e->orig[e->orig_cur ^ 1],
-                       mixed ? e->mirror[nxt] : (float4*)nullptr, e->radius[nxt], w.counters);
+                       mixed ? e->mirror[nxt] : (float4*)nullptr, e->radius[nxt], w.counters, w.lvlmask);
     NBE_HIP(hipGetLastError());
     e->cur = nxt;
     e->orig_cur ^= 1;
@@ -1069,10 +1120,7 @@ static int sort_and_build_t(nbe_engine* e)
 
     const R4* sorted_pos = mixed ? (const R4*)e->mirror[nxt] : (const R4*)e->posm[nxt];
     hipLaunchKernelGGL(radix_tree_kernel, dim3(nb), dim3(256), 0, e->stream, w.keys[0], w.counters, w.bt_first, w.bt_last,
-                       w.bt_parent, w.bt_level);
-    NBE_HIP(hipMemsetAsync(w.lvlmask, 0, ((size_t)n + 1) * 4, e->stream));
-    hipLaunchKernelGGL(mark_cells_kernel, dim3(nb), dim3(256), 0, e->stream, w.counters, w.bt_first, w.bt_parent, w.bt_level,
-                       w.lvlmask);
+                       w.bt_parent, w.bt_level, w.bt_cell, w.lvlmask);
     NBE_HIP(hipGetLastError());
     NBE_TRY((device_exclusive_scan<true>(e, w.lvlmask, w.cellcnt, (size_t)n + 1)));
     constexpr bool PREFIX = !__is_same(NodeT, NodeD);
@@ -1089,7 +1137,7 @@ static int sort_and_build_t(nbe_engine* e)
         NBE_HIP(hipGetLastError());
     }
     hipLaunchKernelGGL((emit_nodes_kernel<R4, NodeT, PREFIX>), dim3(cdiv(2 * (size_t)n, 256)), dim3(256), 0, e->stream, n,
-                       w.counters, sorted_pos, w.bt_first, w.bt_last, w.bt_parent, w.bt_level, w.lvlmask, w.cellcnt, W,
+                       w.counters, sorted_pos, w.bt_first, w.bt_last, w.bt_cell, w.bt_level, w.lvlmask, w.cellcnt, W,
                        e->cfg.theta, (NodeT*)w.nodes, w.node_level, w.node_sum, (const D4*)w.prefix);
     NBE_HIP(hipGetLastError());
     if (!PREFIX) {
@@ -1105,7 +1153,7 @@ static int sort_and_build_t(nbe_engine* e)
         NBE_HIP(hipMemsetAsync(inv, 0xff, (size_t)n * 4, e->stream));
         hipLaunchKernelGGL(ref_inv_kernel, dim3(nb), dim3(256), 0, e->stream, w.counters, e->orig[e->orig_cur], inv);
         hipLaunchKernelGGL((ref_com_kernel<R4, NodeT>), dim3(cdiv((size_t)n * 64, 256)), dim3(256), 0, e->stream, n, w.counters,
-                           sorted_pos, e->orig[e->orig_cur], inv, w.bt_first, w.bt_last, w.bt_parent, w.bt_level, w.lvlmask,
+                           sorted_pos, e->orig[e->orig_cur], inv, w.bt_first, w.bt_last, w.bt_cell, w.bt_level, w.lvlmask,
                            w.cellcnt, (NodeT*)w.nodes);
         NBE_HIP(hipGetLastError());
     }
