@@ -60,13 +60,13 @@ def timed_steps(step_fn, sync_fn, barrier_fn, warmup, steps):
     return time.perf_counter() - t0
 
 
-def traffic_from_profiles(workload):
-    """HBM bytes per launch of the dominant kernel, taken from the committed rocprofv3 --pmc passes
-    (profiles/traffic.json, written by profiles/collect.sh); None if not collected for this workload."""
+def traffic_from_profiles(workload, field="hbm_bytes_per_launch"):
+    """A figure of the committed rocprofv3 --pmc passes (profiles/traffic.json, written by profiles/collect.sh):
+    HBM bytes per launch of the dominant kernel by default; None if not collected for this workload."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         with open(path) as f:
-            return json.load(f).get(workload, {}).get("hbm_bytes_per_launch")
+            return json.load(f).get(workload, {}).get(field)
     except Exception:
         return None
 
@@ -173,7 +173,9 @@ def main():
     roofline = {"bound": "valu", "kernel": "direct_kernel_f32<float,4,64,FUSED,EQM> (equal masses: the mass is folded into G)" if headline_mode == "direct" else "walk_kernel<float>",
                 "achieved": achieved, "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_VALU_PEAK_TFLOPS,
                 "traffic": traffic_from_profiles(workload), "kernel_ms": kernel_ms,
-                "flop_per_interaction": FLOP_PER_INTERACTION}
+                "flop_per_interaction": FLOP_PER_INTERACTION,
+                # clock the kernel held in the profiled run (GRBM_GUI_ACTIVE / 8 / kernel time); the peak assumes 2.4 GHz
+                "profiled_clock_ghz": traffic_from_profiles(workload, "clock_ghz")}
     extra = {}
     if world > 1 or force_dist:
         # the headline step phase by phase (exchanges blocking, maximum over the ranks)
@@ -213,7 +215,11 @@ def main():
             extra[key].update({"ms_sort": st2.ms_sort, "ms_build": st2.ms_build, "ms_force": st2.ms_force,
                                "tree_nodes": int(st2.tree_nodes),
                                "sort_algorithmic_GBps": nb * 200.0 / (st2.ms_sort * 1e-3) / 1e9 if st2.ms_sort > 0 else None,
-                               "build_algorithmic_GBps": nb * 130.0 / (st2.ms_build * 1e-3) / 1e9 if st2.ms_build > 0 else None})
+                               "build_algorithmic_GBps": nb * 130.0 / (st2.ms_build * 1e-3) / 1e9 if st2.ms_build > 0 else None,
+                               # counter-based HBM bytes per step of the two phases (profiles/traffic.json), beside the
+                               # algorithmic 200 and 130 bytes per body
+                               "sort_traffic_bytes": traffic_from_profiles(key, "sort_hbm_bytes_per_step"),
+                               "build_traffic_bytes": traffic_from_profiles(key, "build_hbm_bytes_per_step")})
         e2.close()
         # benchmark configuration 4: the 16M-body cloud, on every GPU count (steps/s at N GPUs over steps/s at 1 GPU
         # is the scaling figure it is judged by)

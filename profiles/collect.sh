@@ -6,7 +6,7 @@
 # tracing domains together with --pmc).  Outputs land in gpurun_out/prof_<tag>/ ; summarise.py condenses them into
 # profiles/<tag>_*.txt and profiles/traffic.json, which are the files that get committed.
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}
 OUT=gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
@@ -21,5 +21,6 @@ run 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write_tree" 
 run 300 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d "$OUT/pmc_sq_direct" -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extra > /dev/null 2> "$OUT/pmc5.err" || exit 1
 run 300 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAIT_INST_ANY --output-format csv -d "$OUT/pmc_sq_tree" -- python3 bench.py --workload tree --steps 2 --warmup 1 --no-cpu-baseline --no-extra > /dev/null 2> "$OUT/pmc6.err" || exit 1
 run 300 rocprofv3 --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d "$OUT/pmc_lds_tree" -- python3 bench.py --workload tree --steps 2 --warmup 1 --no-cpu-baseline --no-extra > /dev/null 2> "$OUT/pmc7.err" || exit 1
+run 300 rocprofv3 --pmc GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_grbm_direct" -- python3 bench.py --steps 2 --warmup 0 --no-cpu-baseline --no-extra > /dev/null 2> "$OUT/pmc8.err" || exit 1
 find "$OUT" -name "*.csv" | head -40 >&2
 python3 profiles/summarise.py "$TAG"

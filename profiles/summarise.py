@@ -11,7 +11,7 @@ import os
 import sys
 from collections import defaultdict
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 base = os.path.join(root, "gpurun_out", f"prof_{tag}")
 
@@ -64,7 +64,7 @@ with open(os.path.join(root, "profiles", f"{tag}_kernel_stats.txt"), "w") as f:
 # ---- counters ----
 pmc = defaultdict(lambda: defaultdict(lambda: [0, 0.0]))
 for sub in ("pmc_fetch_direct", "pmc_write_direct", "pmc_fetch_tree", "pmc_write_tree", "pmc_sq_direct", "pmc_sq_tree",
-            "pmc_lds_tree"):
+            "pmc_lds_tree", "pmc_grbm_direct"):
     for r in rows(f"{sub}/**/*counter_collection.csv"):
         a = pmc[sub][(short(r["Kernel_Name"]), r["Counter_Name"])]
         a[0] += 1; a[1] += float(r["Counter_Value"])
@@ -89,6 +89,25 @@ for workload, kernel, fs, ws in (("direct_fp32_plummer_1M", "direct_kernel", "pm
         traffic[workload] = {"kernel": kernel, "FETCH_SIZE_KiB": fe, "WRITE_SIZE_KiB": wr,
                              "hbm_bytes_per_launch": (2 * fe + wr) * 1024, "tag": tag,
                              "rule": "(2*FETCH_SIZE + WRITE_SIZE) * 1024: gfx950 FETCH_SIZE counts half of a wide coalesced read"}
+# the clock the direct-sum kernel ran at: GRBM_GUI_ACTIVE is summed over the 8 XCDs; / 8 / kernel time (kernel-trace pass)
+ga = mean("pmc_grbm_direct", "direct_kernel", "GRBM_GUI_ACTIVE")
+dk = durations.get("trace_direct", {}).get("direct_kernel")
+if ga is not None and dk and "direct_fp32_plummer_1M" in traffic:
+    traffic["direct_fp32_plummer_1M"]["clock_ghz"] = ga / 8.0 / (dk * 1e-6) / 1e9
+# sort and build phases of the Barnes-Hut step: HBM bytes per step summed over their kernels (launches per step x bytes)
+SORT = ("keys_kernel", "radix_hist_kernel", "scan_rows_kernel", "radix_scatter_kernel", "permute_kernel")
+BUILD = ("radix_tree_kernel", "scan_reduce_kernel", "scan_sums_kernel", "scan_apply_kernel", "psum_reduce_kernel",
+         "psum_scan_sums_kernel", "psum_apply_kernel", "emit_nodes_kernel")
+walk_calls = pmc.get("pmc_fetch_tree", {}).get(("walk_kernel", "FETCH_SIZE"), [0])[0]
+tree_calls = pmc.get("pmc_fetch_tree", {}).get(("radix_tree_kernel", "FETCH_SIZE"), [0])[0]
+if tree_calls:
+    for phase, names in (("sort", SORT), ("build", BUILD)):
+        tot = 0.0
+        for k in names:
+            fa, wa = pmc["pmc_fetch_tree"].get((k, "FETCH_SIZE")), pmc["pmc_write_tree"].get((k, "WRITE_SIZE"))
+            if fa and wa:
+                tot += (2 * fa[1] + wa[1]) * 1024 / tree_calls
+        traffic.setdefault("bh_theta0.5_fp32_plummer_1M", {})[f"{phase}_hbm_bytes_per_step"] = tot
 if traffic:
     with open(os.path.join(root, "profiles", "traffic.json"), "w") as f:
         json.dump(traffic, f, indent=1)
