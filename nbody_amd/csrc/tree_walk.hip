@@ -81,7 +81,20 @@ __device__ __forceinline__ double as_real(unsigned long long v) { return __longl
 // compare, r^2 < edge^2/theta^2; fp64 nodes store the edge and repeat the reference's expression literally.
 // A leaf stores 0 and can never open.
 __device__ __forceinline__ bool node_opens(const RawF& nd, float r2, float) { return r2 < as_real(nd.w2); }
-__device__ __forceinline__ bool node_opens(const RawD& nd, double r2, double theta) { return as_real(nd.w) / sqrt(r2) > theta; }
+// The fp64 expression costs a square root and a division (about half of the visit's instructions), and its verdict
+// is that of  edge^2 > theta^2 * r^2  unless the two sides agree to within the rounding of either form.  So the
+// products decide, and only when some lane of the wave finds them closer than 1e-13 relative (a few hundred times the
+// combined rounding error of both forms), or r^2 is not positive, does the wave evaluate the reference's expression.
+__device__ __forceinline__ bool node_opens(const RawD& nd, double r2, double theta)
+{
+    const double w = as_real(nd.w);
+    const double a = w * w, b = (theta * theta) * r2;
+    bool open = a > b;
+    // (a lane that sits out carries r^2 = infinity: b is infinite and the verdict "closed" is certain)
+    const bool unsure = (fabs(a - b) <= 1e-13 * fmax(a, b) && b < (double)INFINITY) || !(r2 > 0.0);
+    if (__builtin_amdgcn_ballot_w64(unsure) != 0) open = w / sqrt(r2) > theta;
+    return open;
+}
 
 #ifndef WALK_BLOCK
 #define WALK_BLOCK 256
