@@ -18,6 +18,8 @@ struct MultiState {
     std::vector<uint64_t> first, count;      // range of device-order bodies each engine advances
     std::vector<hipEvent_t> advanced;        // engine r: its own range of *_next is written (recorded on its stream)
     std::vector<hipEvent_t> pulled;          // engine r: it has finished copying the other ranges (recorded on its stream)
+    std::vector<hipStream_t> side;           // engine r: stream of its velocity copies (tree mode: they run beside the key sort)
+    std::vector<hipEvent_t> vel_done;        // engine r: its velocity copies have landed (recorded on side[r])
 };
 
 nbe_engine* multi_first(nbe_engine* e) { return e->multi->subs[0]; }
@@ -49,6 +51,8 @@ void multi_destroy(nbe_engine* e)
             (void)hipSetDevice(m->devs[r]);
             if (r < m->advanced.size() && m->advanced[r]) (void)hipEventDestroy(m->advanced[r]);
             if (r < m->pulled.size() && m->pulled[r]) (void)hipEventDestroy(m->pulled[r]);
+            if (r < m->vel_done.size() && m->vel_done[r]) (void)hipEventDestroy(m->vel_done[r]);
+            if (r < m->side.size() && m->side[r]) (void)hipStreamDestroy(m->side[r]);
             if (m->subs[r]) nbe_destroy(m->subs[r]);
         }
         delete m;
@@ -70,6 +74,8 @@ int multi_create(const nbe_config* cfg, nbe_engine** out)
     m->subs.assign((size_t)G, nullptr);
     m->advanced.assign((size_t)G, nullptr);
     m->pulled.assign((size_t)G, nullptr);
+    m->side.assign((size_t)G, nullptr);
+    m->vel_done.assign((size_t)G, nullptr);
     for (int r = 0; r < G; r++) m->devs.push_back(cfg->device_ids ? cfg->device_ids[r] : r);
     int rc = NBE_OK;
     for (int r = 0; r < G && rc == NBE_OK; r++) {
@@ -80,8 +86,10 @@ int multi_create(const nbe_config* cfg, nbe_engine** out)
         rc = nbe_create(&sub, &m->subs[(size_t)r]);
         if (rc != NBE_OK) break;
         if (hipSetDevice(sub.device) != hipSuccess || hipEventCreateWithFlags(&m->advanced[(size_t)r], hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&m->pulled[(size_t)r], hipEventDisableTiming) != hipSuccess) {
-            nbe_set_error("hipEventCreate failed on device %d", sub.device);
+            hipEventCreateWithFlags(&m->pulled[(size_t)r], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&m->vel_done[(size_t)r], hipEventDisableTiming) != hipSuccess ||
+            hipStreamCreateWithFlags(&m->side[(size_t)r], hipStreamNonBlocking) != hipSuccess) {
+            nbe_set_error("hipEventCreate / hipStreamCreate failed on device %d", sub.device);
             rc = NBE_E_DEVICE;
         }
     }
@@ -143,11 +151,17 @@ int multi_step(nbe_engine* e, int nsteps)
             NBE_TRY(nbe_shard_advance(sub));
             NBE_HIP(hipEventRecord(m->advanced[r], sub->stream));
         }
+        // Only the positions gate the next step (keys and radix passes read nothing else).  In tree mode every GPU
+        // therefore pulls the positions on its own stream, commits, starts the next step's key sort, and pulls the
+        // velocities on a side stream meanwhile; its own stream takes the velocities' arrival in before anything else.
+        const bool overlap = e->cfg.mode == NBE_MODE_TREE;
         for (size_t s = 0; s < G; s++) {
             nbe_engine* dst = m->subs[s];
             NBE_HIP(hipSetDevice(m->devs[s]));
             nbe_device_state_t ds;
             NBE_TRY(nbe_device_state(dst, &ds));
+            hipStream_t vstream = overlap ? m->side[s] : dst->stream;
+            if (overlap) NBE_HIP(hipStreamWaitEvent(vstream, m->advanced[s], 0));     // behind this GPU's own use of the buffer
             for (size_t k = 1; k < G; k++) {
                 const size_t r = (s + k) % G;                    // every GPU starts with a different source
                 if (m->count[r] == 0) continue;
@@ -157,12 +171,22 @@ int multi_step(nbe_engine* e, int nsteps)
                 NBE_HIP(hipStreamWaitEvent(dst->stream, m->advanced[r], 0));
                 NBE_HIP(hipMemcpyPeerAsync((char*)ds.pos_mass_next + off, m->devs[s], (const char*)ss.pos_mass_next + off, m->devs[r],
                                            bytes, dst->stream));
+                if (overlap) NBE_HIP(hipStreamWaitEvent(vstream, m->advanced[r], 0));
                 NBE_HIP(hipMemcpyPeerAsync((char*)ds.vel_next + off, m->devs[s], (const char*)ss.vel_next + off, m->devs[r], bytes,
-                                           dst->stream));
+                                           vstream));
             }
-            NBE_HIP(hipEventRecord(m->pulled[s], dst->stream));
+            if (overlap) NBE_HIP(hipEventRecord(m->vel_done[s], vstream));
         }
-        for (size_t r = 0; r < G; r++) NBE_TRY(nbe_shard_commit(m->subs[r]));
+        for (size_t r = 0; r < G; r++) {
+            nbe_engine* sub = m->subs[r];
+            NBE_TRY(nbe_shard_commit(sub));
+            NBE_HIP(hipSetDevice(m->devs[r]));
+            if (overlap) {
+                NBE_TRY(nbe_shard_sort(sub));                     // keys of the new positions, beside the velocity copies
+                NBE_HIP(hipStreamWaitEvent(sub->stream, m->vel_done[r], 0));
+            }
+            NBE_HIP(hipEventRecord(m->pulled[r], sub->stream));   // this GPU no longer reads the others' buffers
+        }
     }
     return NBE_OK;
 }

@@ -169,6 +169,31 @@ def test_coincident_and_very_close_bodies(gpu):
     assert relerr(acc[10:11], lone[10:11]).max() <= 0.05
 
 
+@pytest.mark.parametrize("n,k", [(3000, 700), (20000, 2500)])
+def test_long_runs_of_equal_keys(gpu, monkeypatch, n, k):
+    """k bodies inside one depth-21 cell (edge 1/32 m): their keys are equal, so the radix tree's searches run over
+    ranges longer than the window of keys a workgroup keeps in LDS and over several workgroups.  The bodies become
+    the k leaves of one cell; everybody's force must match the depth-capped oracle, and the single-workgroup and tiled
+    builds must give the same tree bit for bit."""
+    rng = np.random.default_rng(n)
+    pos = rng.uniform(-2e4, 2e4, (n, 3)); mass = rng.uniform(1e3, 2e3, n)
+    first = n // 3
+    pos[first:first + k] = np.array([1234.5, -777.25, 50.0]) + rng.uniform(0, 1 / 64, (k, 3))
+    ref, _, ost = oracle_tree_acc(mass, pos, 0.5)
+    out = []
+    for knob in (None, "0"):
+        if knob is None:
+            monkeypatch.delenv("NBODY_SMALL_TREE_MAX", raising=False)
+        else:
+            monkeypatch.setenv("NBODY_SMALL_TREE_MAX", knob)
+        acc, alive, st, nodes = run_engine(pos, np.zeros((n, 3)), mass, "f64", 0.5)
+        assert alive.all() and st.tree_nodes == n + st.tree_cells
+        assert relerr(acc, ref).max() <= 1e-9
+        assert st.interactions == ost.interactions
+        out.append((acc, nodes))
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+
+
 def test_reference_com_mode_is_close_only_when_cores_dominate(gpu):
     """The reference's centre-of-mass update (tree.go:189-193) omits the rescaling of the old value.  On the
     default scene (two 1e10 kg cores, main.go:35-36) the forces still agree with the engine to ~1e-4 because
