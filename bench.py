@@ -137,7 +137,9 @@ def main():
         eng.upload(b.pos, b.vel, b.mass)
         del b
         if world > 1 or force_dist:
-            stepper = ShardedStepper(EngineShard(eng, device_index=local), always_gather=force_dist)
+            # NBODY_BENCH_SPLIT=1: two ranges per rank, the first one's positions exchanged beside the second force pass
+            stepper = ShardedStepper(EngineShard(eng, device_index=local), always_gather=force_dist,
+                                     split=os.environ.get("NBODY_BENCH_SPLIT") == "1" and n % (512 * max(world, 1)) == 0)
             step_fn = stepper.step
         else:
             eng.set_stream(torch.cuda.current_stream().cuda_stream)

@@ -178,6 +178,8 @@ int nbe_energy(nbe_engine *e, double *kinetic, double *potential, double momentu
  *                                 passes), so that it can run while the velocities of the other engines still arrive
  *   nbe_shard_prepare             tree mode: sort by Morton key, reorder state, build the tree (replicated)
  *   nbe_shard_advance             forces on the shard + fused update, written into *_next at the same indices
+ *   nbe_shard_advance_range       the same for an explicit range [first, first+count), any number of times per step:
+ *                                 a host that owns several ranges can exchange one while the next is computed
  *   (caller all-gathers pos_mass_next and vel_next across engines)
  *   nbe_shard_commit              *_next become current
  * nbe_step is prepare + advance over all bodies + commit. */
@@ -185,6 +187,7 @@ int nbe_set_shard(nbe_engine *e, uint64_t first, uint64_t count);
 int nbe_shard_sort(nbe_engine *e);
 int nbe_shard_prepare(nbe_engine *e);
 int nbe_shard_advance(nbe_engine *e);
+int nbe_shard_advance_range(nbe_engine *e, uint64_t first, uint64_t count);
 int nbe_shard_commit(nbe_engine *e);
 int nbe_device_state(nbe_engine *e, nbe_device_state_t *out);
 

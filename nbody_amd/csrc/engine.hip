@@ -192,7 +192,7 @@ static int upload_state(nbe_engine* e, size_t n, const double* pos, const double
     NBE_TRY(free_state(e));
     e->n = n;
     e->cur = 0; e->orig_cur = 0;
-    e->prepared = false; e->advance_pending = false; e->have_counts = false; e->keys_sorted = false;
+    e->prepared = false; e->advance_pending = false; e->advance_parts = 0; e->have_counts = false; e->keys_sorted = false;
     e->shard_set = false; e->shard_first = 0; e->shard_count = n;
     memset(&e->stats, 0, sizeof(e->stats));
     e->stats.n = n; e->stats.n_alive = n;
@@ -444,13 +444,28 @@ extern "C" int nbe_shard_advance(nbe_engine* e)
     if (e->cfg.collisions) { nbe_set_error("sharded stepping does not support collisions; use nbe_step"); return NBE_E_UNSUPPORTED; }
     NBE_TRY(use_device(e));
     if (!e->prepared) { nbe_set_error("nbe_shard_advance without nbe_shard_prepare"); return NBE_E_INVALID; }
-    if (e->advance_pending) { nbe_set_error("nbe_shard_advance called twice"); return NBE_E_INVALID; }
+    if (e->advance_pending) { nbe_set_error("nbe_shard_advance called twice (advance several ranges with nbe_shard_advance_range)"); return NBE_E_INVALID; }
     uint64_t t0 = e->shard_set ? e->shard_first : 0;
     uint64_t t1 = e->shard_set ? e->shard_first + e->shard_count : e->n;
     if (t1 > e->n) t1 = e->n;
     if (t0 > t1) t0 = t1;
     NBE_TRY(force_pass(e, t0, t1, true));
     e->advance_pending = true;
+    e->advance_parts++;
+    return NBE_OK;
+}
+
+extern "C" int nbe_shard_advance_range(nbe_engine* e, uint64_t first, uint64_t count)
+{
+    if (!e) { nbe_set_error("engine is NULL"); return NBE_E_INVALID; }
+    NBE_NOT_MULTI(e, "nbe_shard_advance_range");
+    if (e->cfg.collisions) { nbe_set_error("sharded stepping does not support collisions; use nbe_step"); return NBE_E_UNSUPPORTED; }
+    NBE_TRY(use_device(e));
+    if (!e->prepared) { nbe_set_error("nbe_shard_advance_range without nbe_shard_prepare"); return NBE_E_INVALID; }
+    if (first > e->n || count > e->n - first) { nbe_set_error("range [%llu, +%llu) outside 0..%zu", (unsigned long long)first, (unsigned long long)count, e->n); return NBE_E_INVALID; }
+    if (count > 0) NBE_TRY(force_pass(e, first, first + count, true));
+    e->advance_pending = true;
+    e->advance_parts += 2;                       // the ranges advanced are not (only) the shard set with nbe_set_shard
     return NBE_OK;
 }
 
@@ -472,14 +487,17 @@ extern "C" int nbe_shard_commit(nbe_engine* e)
     NBE_NOT_MULTI(e, "nbe_shard_commit");
     if (!e->advance_pending) { nbe_set_error("nbe_shard_commit without nbe_shard_advance"); return NBE_E_INVALID; }
     NBE_TRY(use_device(e));
-    if (e->cfg.precision == NBE_PREC_MIXED && e->shard_set && e->shard_count < e->n) {
+    const bool by_ranges = e->advance_parts > 1;      // nbe_shard_advance_range: rows of any range may have arrived from elsewhere
+    if (e->cfg.precision == NBE_PREC_MIXED && (by_ranges || (e->shard_set && e->shard_count < e->n))) {
         const int nxt = e->cur ^ 1;
+        // with explicit ranges every row is converted (the engine's own rows come out as the update wrote them)
         hipLaunchKernelGGL(refresh_mirror_kernel, dim3(cdiv(e->n, 256)), dim3(256), 0, e->stream,
-                           (const double4*)e->posm[nxt], e->mirror[nxt], (int)e->n, (int)e->shard_first,
-                           (int)(e->shard_first + e->shard_count));
+                           (const double4*)e->posm[nxt], e->mirror[nxt], (int)e->n, by_ranges ? 0 : (int)e->shard_first,
+                           by_ranges ? 0 : (int)(e->shard_first + e->shard_count));
         NBE_HIP(hipGetLastError());
     }
     e->cur ^= 1;
+    e->advance_parts = 0;
     e->advance_pending = false;
     e->prepared = false;
     e->stats.steps++;

@@ -178,6 +178,7 @@ struct nbe_engine {
     bool keys_sorted = false;       // tree mode: keys of the current state are sorted already (nbe_shard_sort ran)
     bool prepared = false;          // tree of the current state is valid
     bool advance_pending = false;   // *_next hold an advanced shard waiting for nbe_shard_commit
+    int advance_parts = 0;          // advances since the last commit (nbe_shard_advance_range counts double)
     TreeWork tw;
     nbe_stats_t stats{};
     size_t host_nalive = 0;

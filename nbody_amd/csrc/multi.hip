@@ -120,6 +120,7 @@ int multi_upload(nbe_engine* e, size_t n, const double* pos, const double* vel, 
     MultiState* m = e->multi;
     const size_t G = m->subs.size();
     ranges(n, G, &m->first, &m->count);
+    e->n = 0;                                   // until every engine holds the new bodies
     for (size_t r = 0; r < G; r++) {
         NBE_TRY(nbe_upload(m->subs[r], n, pos, vel, mass, id));
         NBE_TRY(nbe_set_shard(m->subs[r], m->first[r], m->count[r]));

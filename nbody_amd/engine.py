@@ -20,7 +20,7 @@ EXPORTS = ("nbe_default_config", "nbe_create", "nbe_destroy", "nbe_last_error", 
            "nbe_accel", "nbe_step", "nbe_step_timed", "nbe_sync", "nbe_stats", "nbe_energy", "nbe_set_shard",
            "nbe_shard_prepare", "nbe_shard_advance", "nbe_shard_commit", "nbe_device_state", "nbe_set_stream",
            "nbe_time_force_kernel", "nbe_tree_nodes", "nbe_frame_stream_begin", "nbe_frame_stream_end",
-           "nbe_set_radius", "nbe_get_radius", "nbe_shard_sort", "nbe_accel_direct_noalloc")
+           "nbe_set_radius", "nbe_get_radius", "nbe_shard_sort", "nbe_accel_direct_noalloc", "nbe_shard_advance_range")
 
 FRAME_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_size_t, C.POINTER(C.c_float), C.POINTER(C.c_float),
                        C.POINTER(C.c_uint64))
@@ -93,6 +93,7 @@ def load_library():
     lib.nbe_shard_prepare.argtypes = [vp]
     lib.nbe_shard_advance.argtypes = [vp]
     lib.nbe_shard_commit.argtypes = [vp]
+    lib.nbe_shard_advance_range.argtypes = [vp, C.c_uint64, C.c_uint64]
     lib.nbe_device_state.argtypes = [vp, C.POINTER(DeviceState)]
     lib.nbe_set_stream.argtypes = [vp, vp]
     lib.nbe_time_force_kernel.argtypes = [vp, C.c_int, C.POINTER(C.c_float)]
@@ -298,6 +299,9 @@ class Engine:
 
     def shard_commit(self):
         self._check(self._lib.nbe_shard_commit(self._h))
+
+    def shard_advance_range(self, first, count):
+        self._check(self._lib.nbe_shard_advance_range(self._h, int(first), int(count)))
 
     def device_state(self):
         ds = DeviceState()

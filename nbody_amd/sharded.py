@@ -67,6 +67,9 @@ class EngineShard:
     def advance(self):
         self.engine.shard_advance()
 
+    def advance_range(self, first, count):
+        self.engine.shard_advance_range(first, count)
+
     def commit(self):
         self.engine.shard_commit()
 
@@ -83,9 +86,15 @@ class EngineShard:
 class ShardedStepper:
     """Drives one rank's shard.  `shard` is an EngineShard (or anything with the same methods)."""
 
-    def __init__(self, shard, rank=None, world=None, group=None, always_gather=False, align=256):
+    def __init__(self, shard, rank=None, world=None, group=None, always_gather=False, align=256, split=False):
         """always_gather: run the collectives even with a single rank (exercises the RCCL path on one GPU).
-        align: target ranges start at multiples of this many bodies (see shard_range)."""
+        align: target ranges start at multiples of this many bodies (see shard_range).
+        split: give every rank two ranges, one in each half of the sorted order, and exchange the positions of the
+        first while the second is computed (needs n divisible by 2 * world * align and a shard with advance_range);
+        None = do so whenever possible on the RCCL backend.  Off by default: a walk launch ends with a tail of about
+        one wavefront's lifetime (~1 ms at eight waves per SIMD) in which the GPU drains, so two launches of 1M bodies
+        cost 4.3-4.4 ms against 4.15 ms for one of 2M (measured on one MI355X, 16M-body cloud), which gives back half
+        of the ~0.45 ms of exchange that the split hides."""
         self.align = align
         self.always_gather = always_gather
         self.shard = shard
@@ -98,6 +107,22 @@ class ShardedStepper:
         self.even = self.per * self.world == self.n
         self.backend = dist.get_backend(group) if (self.world > 1 or always_gather) else None
         self._pad = {}
+        can_split = (hasattr(shard, "advance_range") and self.n > 0 and self.n % (2 * self.world * align) == 0
+                     and (self.world > 1 or always_gather))
+        if split is None:
+            split = can_split and self.backend == "nccl"
+        if split and not can_split:
+            raise ValueError("split needs n divisible by 2 * world * align and a shard with advance_range")
+        self.split = bool(split)
+        if self.split:
+            # rank r owns [r*q, (r+1)*q) of the first half of the sorted order and the same slice of the second half:
+            # each half is exchanged by one in-place all-gather, the first one while the second range is computed
+            self.half = self.n // 2
+            self.q = self.half // self.world
+            self.ranges = [(k * self.half + self.rank * self.q, self.q) for k in range(2)]
+            self.first, self.count = self.ranges[0]
+        else:
+            self.ranges = [(self.first, self.count)]
 
     def _gather(self, full):
         """All-gather the ranks' row ranges of `full` (n x 4) in place."""
@@ -133,10 +158,49 @@ class ShardedStepper:
             return None
         return dist.all_gather_into_tensor(full, full[self.first:self.first + self.count], group=self.group, async_op=True)
 
+    def _gather_half(self, full, k, async_op):
+        """All-gather half k of `full` (the ranks' slices of it are equal and in rank order) in place; returns a work
+        handle when the exchange runs beside the compute stream, else None."""
+        view = full[k * self.half:(k + 1) * self.half]
+        if self.backend == "gloo" and view.is_cuda:
+            work = view.cpu()
+            dist.all_gather_into_tensor(work, work[self.rank * self.q:(self.rank + 1) * self.q].clone(), group=self.group)
+            view.copy_(work)
+            return None
+        mine = view[self.rank * self.q:(self.rank + 1) * self.q]
+        if async_op and self.backend == "nccl":
+            return dist.all_gather_into_tensor(view, mine, group=self.group, async_op=True)
+        dist.all_gather_into_tensor(view, mine if self.backend == "nccl" else mine.clone(), group=self.group)
+        return None
+
+    def _step_split(self):
+        """One step with two ranges per rank: the positions of the first range travel while the second is computed."""
+        self.shard.prepare()
+        pos, vel = self.shard.next_state()
+        pending = []
+        for k, (first, count) in enumerate(self.ranges):
+            self.shard.advance_range(first, count)
+            pending.append(self._gather_half(pos, k, async_op=True))
+        for w in pending:
+            if w is not None:
+                w.wait()                # stream dependencies, not host waits
+        vpending = [self._gather_half(vel, k, async_op=hasattr(self.shard, "sort_ahead")) for k in range(2)]
+        self.shard.commit()
+        if any(w is not None for w in vpending):
+            self.shard.sort_ahead()
+            for w in vpending:
+                if w is not None:
+                    w.wait()
+
     def step(self, nsteps=1):
         """Per step: build (replicated), advance the own range, exchange positions, then velocities.  Only the
         positions are needed to start the next step (keys and radix passes), so the velocity exchange runs beside
-        that sort when the shard offers `sort_ahead`; the stream waits for it before the state is reordered."""
+        that sort when the shard offers `sort_ahead`; the stream waits for it before the state is reordered.
+        With `split` the position exchange itself is half hidden behind the force pass (_step_split)."""
+        if self.split:
+            for _ in range(nsteps):
+                self._step_split()
+            return
         for _ in range(nsteps):
             self.shard.prepare()
             self.shard.advance()
@@ -156,12 +220,23 @@ class ShardedStepper:
         ev[0].record()
         self.shard.prepare()
         ev[1].record()
-        self.shard.advance()
+        if self.split:
+            for first, count in self.ranges:
+                self.shard.advance_range(first, count)
+        else:
+            self.shard.advance()
         ev[2].record()
         pos, vel = self.shard.next_state()
-        self._gather(pos)
-        ev[3].record()
-        self._gather(vel)
+        if self.split:
+            for k in range(2):
+                self._gather_half(pos, k, async_op=False)
+            ev[3].record()
+            for k in range(2):
+                self._gather_half(vel, k, async_op=False)
+        else:
+            self._gather(pos)
+            ev[3].record()
+            self._gather(vel)
         ev[4].record()
         self.shard.commit()
         torch.cuda.synchronize()

@@ -50,6 +50,12 @@ class OracleShard:
         self.nxt[0][s, :3] = torch.from_numpy(p); self.nxt[0][s, 3] = self.cur[0][s, 3]
         self.nxt[1][s, :3] = torch.from_numpy(v)
 
+    def advance_range(self, first, count):
+        keep = (self.first, self.count)
+        self.first, self.count = first, count
+        self.advance()
+        self.first, self.count = keep
+
     def next_state(self):
         return self.nxt
 
@@ -64,7 +70,9 @@ def main():
     bodies = physics.makebodies(n - 2, seed=11)
     if kind == "oracle":
         shard = OracleShard(bodies, mode, 0.5, 3600.0)
-        stepper = ShardedStepper(shard, align=1)      # the CPU stand-in has no wavefronts to align the ranges with
+        # the CPU stand-in has no wavefronts to align the ranges with; "split" as a seventh argument rehearses the
+        # two-ranges-per-rank exchange
+        stepper = ShardedStepper(shard, align=1, split="split" in sys.argv[6:])
         stepper.step(nsteps)
         pos = shard.cur[0][:, :3].numpy(); vel = shard.cur[1][:, :3].numpy()
     else:
@@ -73,7 +81,7 @@ def main():
         prec = sys.argv[6]
         eng = Engine(mode=mode, precision=prec, theta=0.5)
         eng.upload(bodies.pos, bodies.vel, bodies.mass)
-        stepper = ShardedStepper(EngineShard(eng))
+        stepper = ShardedStepper(EngineShard(eng), split="split" in sys.argv[7:])
         stepper.step(nsteps)
         pos, vel, _, _ = eng.download()
     np.savez(f"{out_prefix}.rank{rank}.npz", pos=pos, vel=vel, first=stepper.first, count=stepper.count)

@@ -83,13 +83,14 @@ def test_call_order_errors(gpu):
 
 
 @pytest.mark.parametrize("mode,precision,n", [("tree", "f32", 4096), ("tree", "f64", 1001), ("direct", "f32", 4096),
-                                              ("direct", "mixed", 999), ("tree", "mixed", 3001)])
+                                              ("direct", "mixed", 999), ("tree", "mixed", 3001), ("tree", "mixed", 4096)])
 def test_two_ranks_on_one_gpu_match_single_engine(gpu, tmp_path, mode, precision, n):
     """world_size 2 over gloo, both ranks on cuda:0, real engines: each advances half the targets and the
     halves are all-gathered; the result must equal one engine stepping everything.  The tree walk gives each
     body its private result whatever wave it sits in, so tree mode must agree bit for bit; the direct sum
     may split its source range differently for a half-size launch (summation order), hence a tolerance."""
-    res = run_ranks(tmp_path, 2, [mode, str(n), "3", "gpu", precision], timeout=240)
+    # 4096 bodies divide into two 256-aligned ranges per rank: that case also runs the stepper's split exchange
+    res = run_ranks(tmp_path, 2, [mode, str(n), "3", "gpu", precision] + (["split"] if n % 1024 == 0 else []), timeout=240)
     assert np.array_equal(res[0]["pos"], res[1]["pos"]) and np.array_equal(res[0]["vel"], res[1]["vel"])
     b = physics.makebodies(n - 2, seed=11)
     with Engine(mode=mode, precision=precision, theta=0.5) as e:
@@ -228,7 +229,8 @@ def test_steps_can_be_captured_in_a_hip_graph(gpu, mode):
 @pytest.mark.parametrize("mode,precision,extra", [("tree", "f32", {}), ("tree", "mixed", {}), ("direct", "f32", {}),
                                                   ("tree", "f32", {"per_wave": True}),
                                                   ("tree", "f64", {"ref_com": True, "drop_tail": True})])
-def test_single_rank_rccl_stepper_with_overlapped_velocity_exchange(gpu, mode, precision, extra):
+@pytest.mark.parametrize("n", [20000, 20480])
+def test_single_rank_rccl_stepper_with_overlapped_velocity_exchange(gpu, mode, precision, extra, n):
     """The RCCL path of ShardedStepper on one GPU (one-rank "nccl" group, collectives forced): positions are
     exchanged first, the velocity exchange runs beside the next step's key sort (nbe_shard_sort), and the result
     equals plain nbe_step bit for bit; also with the per-wave walk and with the reference's own arithmetic (whose
@@ -245,15 +247,17 @@ def test_single_rank_rccl_stepper_with_overlapped_velocity_exchange(gpu, mode, p
         except Exception as ex:                      # no rendezvous on this box: nothing to do with the engine
             pytest.skip(f"cannot create a one-rank RCCL group here: {ex}")
     try:
-        b = physics.plummer(20000, seed=8, a=3e3)
+        # 20,480 bodies divide into two 256-aligned halves: the stepper then advances two ranges per rank and sends
+        # the first one's positions while the second is computed
+        b = physics.plummer(n, seed=8, a=2e3)
         with Engine(mode=mode, precision=precision, theta=0.6, **extra) as plain:
             plain.upload(b.pos, b.vel, b.mass)
             plain.step(6)
             want = plain.download()
         with Engine(mode=mode, precision=precision, theta=0.6, **extra) as e:
             e.upload(b.pos, b.vel, b.mass)
-            st = ShardedStepper(EngineShard(e, device_index=0), rank=0, world=1, always_gather=True)
-            assert st.backend == "nccl"
+            st = ShardedStepper(EngineShard(e, device_index=0), rank=0, world=1, always_gather=True, split=n % 512 == 0)
+            assert st.backend == "nccl" and st.split == (n % 512 == 0)
             st.step(6)
             torch.cuda.synchronize()
             got = e.download()

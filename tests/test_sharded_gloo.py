@@ -64,11 +64,17 @@ def test_shard_ranges_cover_everything_once():
             assert seen == list(range(n))
 
 
-@pytest.mark.parametrize("mode,n", [("direct", 64), ("direct", 63), ("tree", 64), ("tree", 61)])
-def test_two_ranks_reproduce_single_process(tmp_path, mode, n):
-    res = run_ranks(tmp_path, 2, [mode, str(n), "3", "oracle"])
+@pytest.mark.parametrize("mode,n,split", [("direct", 64, False), ("direct", 63, False), ("tree", 64, False), ("tree", 61, False),
+                                         ("direct", 64, True), ("tree", 64, True)])
+def test_two_ranks_reproduce_single_process(tmp_path, mode, n, split):
+    """split: every rank owns a slice of each half of the body order and exchanges the halves one after the other (the
+    arrangement that lets the first exchange run beside the second force pass on RCCL)."""
+    res = run_ranks(tmp_path, 2, [mode, str(n), "3", "oracle", "-"] + (["split"] if split else []))
     assert np.array_equal(res[0]["pos"], res[1]["pos"]) and np.array_equal(res[0]["vel"], res[1]["vel"])
-    assert int(res[0]["first"]) == 0 and int(res[1]["first"]) == int(res[0]["count"])
+    if split:
+        assert int(res[0]["first"]) == 0 and int(res[0]["count"]) == n // 4 and int(res[1]["first"]) == n // 4
+    else:
+        assert int(res[0]["first"]) == 0 and int(res[1]["first"]) == int(res[0]["count"])
     b = physics.makebodies(n - 2, seed=11)
     pos, vel = b.pos.copy(), b.vel.copy()
     for _ in range(3):
