@@ -21,6 +21,8 @@
 // reordered (permute_kernel)
 #define COUNTER_SORTED_ALIVE 8
 
+__device__ __forceinline__ unsigned xcd_contiguous_block(void);
+
 #define SORT_KPT 8                     // keys per thread
 #define SORT_TILE (256 * SORT_KPT)     // keys per workgroup
 #define SCAN_TILE 2048                 // elements per workgroup in the device-wide scan (256 threads x 8)
@@ -227,19 +229,20 @@ __global__ __launch_bounds__(256) void keys_kernel(const R4* __restrict__ posm, 
 
 // ---- LSD radix sort, 8-bit digits, (key, index) pairs ---------------------------------------------------------
 __global__ __launch_bounds__(256) void radix_hist_kernel(const uint64_t* __restrict__ keys, int n, int shift, int nblocks,
-                                                         uint32_t* __restrict__ block_hist)
+                                                         uint32_t* __restrict__ block_hist, int by_xcd)
 {
     __shared__ uint32_t h[256];
     h[threadIdx.x] = 0;
     __syncthreads();
-    const int base = blockIdx.x * SORT_TILE;
+    const int tile = by_xcd ? (int)xcd_contiguous_block() : (int)blockIdx.x;     // the XCD that will scatter this tile also counts it
+    const int base = tile * SORT_TILE;
 #pragma unroll
     for (int k = 0; k < SORT_KPT; k++) {
         int i = base + k * 256 + threadIdx.x;
         if (i < n) atomicAdd(&h[(uint32_t)(keys[i] >> shift) & 255u], 1u);
     }
     __syncthreads();
-    block_hist[(size_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
+    block_hist[(size_t)threadIdx.x * nblocks + tile] = h[threadIdx.x];
 }
 
 // Stable scatter.  Each wave owns a contiguous quarter of the tile and walks it 64 keys at a time; within a
@@ -249,7 +252,7 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const uint64_t* __re
                                                             uint64_t* __restrict__ kout, uint32_t* __restrict__ vout,
                                                             const uint32_t* __restrict__ offsets,
                                                             const uint32_t* __restrict__ totals, int n, int shift, int nblocks,
-                                                            int* __restrict__ alive_out)
+                                                            int* __restrict__ alive_out, int by_xcd)
 {
     __shared__ uint32_t wcount[4][256];
     __shared__ uint32_t wbase[4][256];
@@ -257,12 +260,17 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const uint64_t* __re
     __shared__ uint64_t skey[SORT_TILE];
     __shared__ uint32_t sval[SORT_TILE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // Neighbouring tiles write neighbouring slots of every digit's run: with the workgroups of one XCD on a contiguous
+    // eighth of the tiles, the halves of a line meet in one L2 instead of being written back from two (16M bodies:
+    // 159 -> 140 us per pass, and the histogram pass over the same tiles 53 -> 39 us).  Sorts of a few hundred tiles,
+    // which fit the caches anyway, ran 5 % slower that way and keep the plain numbering.
+    const int tile = by_xcd ? (int)xcd_contiguous_block() : (int)blockIdx.x;
 #pragma unroll
     for (int w = 0; w < 4; w++) wcount[w][tid] = 0;
     __syncthreads();
 
     volatile uint32_t* wc = wcount[wave];
-    const int base = blockIdx.x * SORT_TILE + wave * (SORT_TILE / 4);
+    const int base = tile * SORT_TILE + wave * (SORT_TILE / 4);
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     uint64_t k[SORT_KPT];
     uint32_t v[SORT_KPT], rank[SORT_KPT];
@@ -302,10 +310,10 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const uint64_t* __re
         // keys with a smaller digit anywhere + keys with this digit in earlier tiles = where this digit's run goes
         // in the output; minus its first slot in the tile: global = slot + gdelta
         const uint32_t below = block_excl_scan(totals[tid], &tot);
-        gdelta[tid] = below + offsets[(size_t)tid * nblocks + blockIdx.x] - dstart;
+        gdelta[tid] = below + offsets[(size_t)tid * nblocks + tile] - dstart;
         // Last pass (key bits 56..63): every live key (63 bits) has a digit below 255, the all-ones key of a body
         // outside the bound has 255, so the keys below digit 255 are the live bodies.
-        if (alive_out && blockIdx.x == 0 && tid == 255) *alive_out = (int)below;
+        if (alive_out && tile == 0 && tid == 255) *alive_out = (int)below;
     }
     __syncthreads();
     // Stage the tile in digit-sorted order in LDS, then write it out with consecutive threads on consecutive
@@ -322,7 +330,7 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const uint64_t* __re
         }
     }
     __syncthreads();
-    const int tile_n = min(SORT_TILE, n - blockIdx.x * SORT_TILE);
+    const int tile_n = min(SORT_TILE, n - tile * SORT_TILE);
 #pragma unroll
     for (int r = 0; r < SORT_KPT; r++) {
         const int slot = r * 256 + tid;
@@ -445,6 +453,17 @@ __global__ __launch_bounds__(1024) void small_sort_kernel(const R4* __restrict__
     }
 }
 
+// Workgroups are dealt round-robin to the 8 XCDs, each with its own L2.  emit_nodes_kernel, whose neighbouring
+// workgroups read the same lines of the prefix sums and cell counts, runs the workgroups of one XCD over one
+// contiguous eighth of the index range instead, so that a line is fetched into one L2, not into several (16M
+// bodies: 874 -> 759 us; the state gather and the radix tree kernel did not gain from it: 519 -> 526, 433 -> 454 us).
+// Bijective for any grid size; a placement assumption that only affects speed.
+__device__ __forceinline__ unsigned xcd_contiguous_block(void)
+{
+    const unsigned nwg = gridDim.x, q8 = nwg / 8, r8 = nwg % 8, xcd = blockIdx.x % 8;
+    return (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + blockIdx.x / 8;
+}
+
 // Reorders the state into sorted order (gather): dst[i] = src[idx[i]].
 template <typename S4>
 __global__ __launch_bounds__(256) void permute_kernel(const uint32_t* __restrict__ idx, int n, const S4* __restrict__ pos_in,
@@ -465,6 +484,7 @@ __global__ __launch_bounds__(256) void permute_kernel(const uint32_t* __restrict
         counters[1] = 0; counters[2] = 0; counters[3] = 0;
     }
     if (i >= n) return;
+    // (four bodies per thread with all gathers in flight together: 590 against 514 us at 16M bodies)
     const uint32_t j = idx[i];
     pos_out[i] = pos_in[j];
     vel_out[i] = vel_in[j];
@@ -750,7 +770,11 @@ __global__ __launch_bounds__(256) void emit_nodes_kernel(int n, int* __restrict_
                                                          const D4* __restrict__ prefix)
 {
     const int na = counters[0];
-    const int t = blockIdx.x * 256 + threadIdx.x;
+    // Even workgroups (in the XCD-contiguous numbering) emit 256 leaves, odd ones the cells among the 256 binary nodes of
+    // the same index range: the two kinds read the same lines of the cell counts, and every XCD gets its share of both.
+    const unsigned vb = xcd_contiguous_block();
+    const int local = (int)((vb >> 1) * 256 + threadIdx.x);
+    const int t = (vb & 1u) ? n + local : (local < n ? local : 2 * n);      // >= 2n: nothing to do
     if (t == 0) {
         const int cells = na > 0 ? (int)cellcnt[na] : 0;
         counters[1] = na + cells;
@@ -1079,15 +1103,16 @@ static int sort_keys_t(nbe_engine* e)
     NBE_HIP(hipGetLastError());
     // 63-bit keys plus the all-ones dead key: 8 passes of 8 bits, ending back in buffer 0.
     const int nblocks = (int)cdiv(n, SORT_TILE);
+    const int by_xcd = nblocks >= 2048;
     int in = 0;
     for (int pass = 0; pass < 8; pass++) {
         const int shift = pass * 8;
         hipLaunchKernelGGL(radix_hist_kernel, dim3(nblocks), dim3(256), 0, e->stream, w.keys[in], n, shift, nblocks,
-                           w.block_hist);
+                           w.block_hist, by_xcd);
         hipLaunchKernelGGL(scan_rows_kernel, dim3(256), dim3(256), 0, e->stream, w.block_hist, nblocks, w.scan_tmp);
         hipLaunchKernelGGL(radix_scatter_kernel, dim3(nblocks), dim3(256), 0, e->stream, w.keys[in], w.sidx[in],
                            w.keys[in ^ 1], w.sidx[in ^ 1], w.block_hist, w.scan_tmp, n, shift, nblocks,
-                           pass == 7 ? w.counters + COUNTER_SORTED_ALIVE : (int*)nullptr);
+                           pass == 7 ? w.counters + COUNTER_SORTED_ALIVE : (int*)nullptr, by_xcd);
         NBE_HIP(hipGetLastError());
         in ^= 1;
     }
@@ -1136,7 +1161,7 @@ static int sort_and_build_t(nbe_engine* e)
         }
         NBE_HIP(hipGetLastError());
     }
-    hipLaunchKernelGGL((emit_nodes_kernel<R4, NodeT, PREFIX>), dim3(cdiv(2 * (size_t)n, 256)), dim3(256), 0, e->stream, n,
+    hipLaunchKernelGGL((emit_nodes_kernel<R4, NodeT, PREFIX>), dim3(2 * cdiv((size_t)n, 256)), dim3(256), 0, e->stream, n,
                        w.counters, sorted_pos, w.bt_first, w.bt_last, w.bt_cell, w.bt_level, w.lvlmask, w.cellcnt, W,
                        e->cfg.theta, (NodeT*)w.nodes, w.node_level, w.node_sum, (const D4*)w.prefix);
     NBE_HIP(hipGetLastError());
