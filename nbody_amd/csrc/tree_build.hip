@@ -212,19 +212,31 @@ __device__ __forceinline__ uint64_t body_key(double x, double y, double z, doubl
 
 // One key per body.  A body is kept iff lo <= p < hi on every axis (contains, tree.go:65-72; NaN fails);
 // others get the all-ones key, sort to the end and stay out of the tree for good (tree.go:290-292).
-// (Counting the live bodies here with one atomic per wave cost 180 us at 1M bodies: 16k atomics on one word.)
+// A workgroup handles one tile of the radix sort and also counts the tile's lowest digits (the histogram of the first
+// pass), while the keys are still in registers; the first scatter pass takes a body's index from its position, so no
+// index array is written here.  The number of live bodies falls out of the sort's last pass (radix_scatter_kernel).
 template <typename R4>
 __global__ __launch_bounds__(256) void keys_kernel(const R4* __restrict__ posm, int n, double lox, double loy, double loz,
-                                                   double width, uint64_t* __restrict__ keys, uint32_t* __restrict__ idx,
-                                                   int* __restrict__ counters)
+                                                   double width, uint64_t* __restrict__ keys, int nblocks,
+                                                   uint32_t* __restrict__ block_hist, int by_xcd)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n) {
-        R4 p = posm[i];
-        keys[i] = body_key((double)p.x, (double)p.y, (double)p.z, lox, loy, loz, width);
-        idx[i] = (uint32_t)i;
+    __shared__ uint32_t h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const int tile = by_xcd ? (int)xcd_contiguous_block() : (int)blockIdx.x;
+    const int base = tile * SORT_TILE;
+#pragma unroll
+    for (int k = 0; k < SORT_KPT; k++) {
+        const int i = base + k * 256 + threadIdx.x;
+        if (i < n) {
+            const R4 p = posm[i];
+            const uint64_t key = body_key((double)p.x, (double)p.y, (double)p.z, lox, loy, loz, width);
+            keys[i] = key;
+            atomicAdd(&h[(uint32_t)key & 255u], 1u);
+        }
     }
-    (void)counters;   // the number of live bodies falls out of the sort's last pass (radix_scatter_kernel)
+    __syncthreads();
+    block_hist[(size_t)threadIdx.x * nblocks + tile] = h[threadIdx.x];
 }
 
 // ---- LSD radix sort, 8-bit digits, (key, index) pairs ---------------------------------------------------------
@@ -279,7 +291,7 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const uint64_t* __re
         const int i = base + r * 64 + lane;
         const bool valid = i < n;
         k[r] = valid ? kin[i] : KEY_DEAD;
-        v[r] = valid ? vin[i] : 0u;
+        v[r] = valid ? (vin ? vin[i] : (uint32_t)i) : 0u;       // first pass: the body's index is its position
         const uint32_t digit = (uint32_t)(k[r] >> shift) & 255u;
         unsigned long long peers = __ballot(valid);
 #pragma unroll
@@ -1086,7 +1098,6 @@ static int sort_keys_t(nbe_engine* e)
     TreeWork& w = e->tw;
     const int n = (int)e->n;
     const int cur = e->cur;
-    const unsigned nb = cdiv(n, 256);
     const bool mixed = e->cfg.precision == NBE_PREC_MIXED;
     const R4* force_pos = mixed ? (const R4*)e->mirror[cur] : (const R4*)e->posm[cur];
     const double W = e->cfg.bound_width;
@@ -1098,21 +1109,22 @@ static int sort_keys_t(nbe_engine* e)
         NBE_HIP(hipGetLastError());
         return NBE_OK;
     }
-    hipLaunchKernelGGL((keys_kernel<R4>), dim3(nb), dim3(256), 0, e->stream, force_pos, n, lox, loy, loz, W, w.keys[0],
-                       w.sidx[0], w.counters);
-    NBE_HIP(hipGetLastError());
     // 63-bit keys plus the all-ones dead key: 8 passes of 8 bits, ending back in buffer 0.
     const int nblocks = (int)cdiv(n, SORT_TILE);
     const int by_xcd = nblocks >= 2048;
+    hipLaunchKernelGGL((keys_kernel<R4>), dim3(nblocks), dim3(256), 0, e->stream, force_pos, n, lox, loy, loz, W, w.keys[0],
+                       nblocks, w.block_hist, by_xcd);
+    NBE_HIP(hipGetLastError());
     int in = 0;
     for (int pass = 0; pass < 8; pass++) {
         const int shift = pass * 8;
-        hipLaunchKernelGGL(radix_hist_kernel, dim3(nblocks), dim3(256), 0, e->stream, w.keys[in], n, shift, nblocks,
-                           w.block_hist, by_xcd);
+        if (pass > 0)       // the key kernel has counted the digits of the first pass
+            hipLaunchKernelGGL(radix_hist_kernel, dim3(nblocks), dim3(256), 0, e->stream, w.keys[in], n, shift, nblocks,
+                               w.block_hist, by_xcd);
         hipLaunchKernelGGL(scan_rows_kernel, dim3(256), dim3(256), 0, e->stream, w.block_hist, nblocks, w.scan_tmp);
-        hipLaunchKernelGGL(radix_scatter_kernel, dim3(nblocks), dim3(256), 0, e->stream, w.keys[in], w.sidx[in],
-                           w.keys[in ^ 1], w.sidx[in ^ 1], w.block_hist, w.scan_tmp, n, shift, nblocks,
-                           pass == 7 ? w.counters + COUNTER_SORTED_ALIVE : (int*)nullptr, by_xcd);
+        hipLaunchKernelGGL(radix_scatter_kernel, dim3(nblocks), dim3(256), 0, e->stream, w.keys[in],
+                           pass > 0 ? w.sidx[in] : (const uint32_t*)nullptr, w.keys[in ^ 1], w.sidx[in ^ 1], w.block_hist,
+                           w.scan_tmp, n, shift, nblocks, pass == 7 ? w.counters + COUNTER_SORTED_ALIVE : (int*)nullptr, by_xcd);
         NBE_HIP(hipGetLastError());
         in ^= 1;
     }
