@@ -734,7 +734,9 @@ static int tree_nodes_impl(nbe_engine* e, double* out, size_t cap, size_t* count
         NBE_HIP(hipStreamSynchronize(e->stream));
         for (size_t i = 0; i < m; i++) {
             out[6 * i] = h[i].x; out[6 * i + 1] = h[i].y; out[6 * i + 2] = h[i].z; out[6 * i + 3] = h[i].m;
-            out[6 * i + 4] = sqrt((double)h[i].w2) * e->cfg.theta; out[6 * i + 5] = (double)h[i].skip;
+            // the stored threshold is (edge / theta)^2 + eps^2 for a cell, 0 for a leaf
+            const double q = (double)h[i].w2 - (h[i].w2 > 0.0f ? e->cfg.eps * e->cfg.eps : 0.0);
+            out[6 * i + 4] = sqrt(q > 0.0 ? q : 0.0) * e->cfg.theta; out[6 * i + 5] = (double)h[i].skip;
         }
     }
     return NBE_OK;

@@ -589,13 +589,15 @@ __global__ __launch_bounds__(256) void radix_tree_kernel(const uint64_t* __restr
 
 // fp32 nodes store (edge / theta)^2 for the walk's one-compare opening test; theta = 0 ("always open") maps to
 // the largest float.  fp64 nodes store the edge itself.
-template <typename NodeT> __device__ __forceinline__ void set_edge(NodeT& nd, double w, double theta);
-template <> __device__ __forceinline__ void set_edge<NodeF>(NodeF& nd, double w, double theta)
+// With softening the walk's r^2 carries eps^2 (it is the r^2 of the force); the stored threshold of a cell carries it too,
+// so that the test still compares the bare distance with the edge and costs no subtraction per visit.
+template <typename NodeT> __device__ __forceinline__ void set_edge(NodeT& nd, double w, double theta, double eps2);
+template <> __device__ __forceinline__ void set_edge<NodeF>(NodeF& nd, double w, double theta, double eps2)
 {
     const double q = theta > 0.0 ? (w / theta) * (w / theta) : (w > 0.0 ? 3.0e38 : 0.0);
-    nd.w2 = (float)fmin(q, 3.0e38);
+    nd.w2 = (float)fmin(w > 0.0 ? q + eps2 : q, 3.0e38);
 }
-template <> __device__ __forceinline__ void set_edge<NodeD>(NodeD& nd, double w, double) { nd.w = w; }
+template <> __device__ __forceinline__ void set_edge<NodeD>(NodeD& nd, double w, double, double) { nd.w = w; }
 
 // ---- fp64 prefix sums of (m, m*x, m*y, m*z) over the sorted bodies ---------------------------------------------
 // A cell covers a contiguous range [a, b] of sorted bodies, so its mass and first moments are differences of
@@ -777,7 +779,7 @@ __global__ __launch_bounds__(256) void emit_nodes_kernel(int n, int* __restrict_
                                                          const int* __restrict__ bt_first, const int* __restrict__ bt_last,
                                                          const uint8_t* __restrict__ bt_cell, const uint8_t* __restrict__ bt_level,
                                                          const uint32_t* __restrict__ lvlmask, const uint32_t* __restrict__ cellcnt,
-                                                         double bound_width, double theta, NodeT* __restrict__ nodes,
+                                                         double bound_width, double theta, double eps2, NodeT* __restrict__ nodes,
                                                          uint8_t* __restrict__ node_level, double* __restrict__ node_sum,
                                                          const D4* __restrict__ prefix)
 {
@@ -794,7 +796,7 @@ __global__ __launch_bounds__(256) void emit_nodes_kernel(int n, int* __restrict_
         // sentinel behind the last node: massless, never opens, skips to itself (a finished walk parks here)
         NodeT snt;
         snt.x = 0; snt.y = 0; snt.z = 0; snt.m = 0;
-        set_edge<NodeT>(snt, 0.0, theta);
+        set_edge<NodeT>(snt, 0.0, theta, eps2);
         snt.skip = na + cells;
         nodes[na + cells] = snt;
     }
@@ -804,7 +806,7 @@ __global__ __launch_bounds__(256) void emit_nodes_kernel(int n, int* __restrict_
         const R4 p = posm[t];
         NodeT nd;
         nd.x = p.x; nd.y = p.y; nd.z = p.z; nd.m = p.w;
-        set_edge<NodeT>(nd, 0.0, theta);
+        set_edge<NodeT>(nd, 0.0, theta, eps2);
         nd.skip = pos + 1;
         nodes[pos] = nd;
         if (!PREFIX) {
@@ -831,7 +833,7 @@ __global__ __launch_bounds__(256) void emit_nodes_kernel(int n, int* __restrict_
         const double inv = m != 0.0 ? 1.0 / m : 0.0;
         nd.x = (hi.x - lo.x) * inv; nd.y = (hi.y - lo.y) * inv; nd.z = (hi.z - lo.z) * inv; nd.m = m;
     }
-    set_edge<NodeT>(nd, bound_width * (1.0 / (double)(1u << lvl)), theta);   // edge: exact halving of a power of two
+    set_edge<NodeT>(nd, bound_width * (1.0 / (double)(1u << lvl)), theta, eps2);   // edge: exact halving of a power of two
     nd.skip = (b + 1) + (int)cellcnt[b + 1];
     nodes[pos] = nd;
     if (!PREFIX) node_level[pos] = (uint8_t)lvl;
@@ -1175,7 +1177,7 @@ static int sort_and_build_t(nbe_engine* e)
     }
     hipLaunchKernelGGL((emit_nodes_kernel<R4, NodeT, PREFIX>), dim3(2 * cdiv((size_t)n, 256)), dim3(256), 0, e->stream, n,
                        w.counters, sorted_pos, w.bt_first, w.bt_last, w.bt_cell, w.bt_level, w.lvlmask, w.cellcnt, W,
-                       e->cfg.theta, (NodeT*)w.nodes, w.node_level, w.node_sum, (const D4*)w.prefix);
+                       e->cfg.theta, e->cfg.eps * e->cfg.eps, (NodeT*)w.nodes, w.node_level, w.node_sum, (const D4*)w.prefix);
     NBE_HIP(hipGetLastError());
     if (!PREFIX) {
         for (int level = 21; level >= 0; level--) {

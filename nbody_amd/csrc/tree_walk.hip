@@ -103,7 +103,7 @@ __device__ __forceinline__ bool node_opens(const RawD& nd, double r2, double the
 // COUNT: instrumented pass: also counts the force evaluations (tree.go:232-238 executions) of the wave and sums
 // each body's potential (sum of mass / softened distance over the same accepted nodes, returned in the w
 // component of the acceleration record, without the factor -G); the production step runs without it.
-// SOFT: Plummer softening is on, so the opening test must undo the eps^2 folded into r^2 (with eps = 0 the
+// SOFT (fp64 node records only): Plummer softening is on, so the opening test must undo the eps^2 folded into r^2 (with eps = 0 the
 // floor is 1e-12 m^2, far below the resolution of any cell edge, and the test uses r^2 as is).
 // NS: independent traversals (groups of 64 bodies) interleaved in one wave, each with its own cursor, node
 // registers and sit-out index; a group that finishes first parks on the sentinel record behind the last node
@@ -419,7 +419,9 @@ static int launch_walk(nbe_engine* e, const void* src, uint64_t t0, uint64_t t1,
     const double eps = e->cfg.eps;
     const double tiny = __is_same(R, float) ? 1e-12 : 1e-60;
     const R floor2 = (R)(eps * eps > tiny ? eps * eps : tiny);
-    const bool soft = eps * eps > tiny;
+    // fp32 node records carry eps^2 in their opening threshold (set_edge in tree_build.hip); only the fp64 walk, which
+    // repeats the reference's expression on the bare distance, takes the softening out of r^2 again
+    const bool soft = eps * eps > tiny && !__is_same(NodeT, NodeF);
     const bool group = e->cfg.walk_criterion == NBE_WALK_PER_WAVE;
     const A G = (A)e->cfg.G, dt = (A)e->cfg.dt;
     const bool mixed = e->cfg.precision == NBE_PREC_MIXED;
