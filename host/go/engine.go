@@ -34,7 +34,7 @@ type gpuOptions struct {
 	precision int  // C.NBE_PREC_F64 (the reference computes in float64; gpuOptionsFromFlags' default), C.NBE_PREC_MIXED, C.NBE_PREC_F32
 	asGo      bool // tree mode: running cell centres (tree.go:189-193) and unwalked last n mod 4 bodies (main.go:134-148)
 	perWave   bool // tree mode: the bodies of a wavefront open cells together (faster, finer, not the reference's set)
-	gpus      int  // > 1: the engine drives GPUs 0 .. gpus-1 itself (body ranges fanned out as main.go:134-149 fans them over goroutines); needs -nocollision
+	gpus      int  // > 1: the engine drives GPUs 0 .. gpus-1 itself (body ranges fanned out as main.go:134-149 fans them over goroutines); with collisions on, tree mode only
 }
 
 // gpuEngine owns one nbe_engine.  All calls happen on one locked OS thread, as the reference drives the step

@@ -20,7 +20,7 @@ var (
 	gpuPrecision = flag.String("precision", "f64", "GPU arithmetic: f64, mixed (fp32 pair terms, fp64 sums and state) or f32")
 	gpuAsGo      = flag.Bool("asgo", false, "tree mode: the reference's running cell centres and unwalked last n mod 4 bodies")
 	gpuPerWave   = flag.Bool("perwave", false, "tree mode: the bodies of a wavefront open cells together (not the reference's interaction set)")
-	gpuCount     = flag.Int("gpus", 1, "GPUs driven by the one engine (needs -nocollision when above 1)")
+	gpuCount     = flag.Int("gpus", 1, "GPUs driven by the one engine (with collisions on: -tree only)")
 	gpuBlocking  = flag.Bool("blockingframes", false, "take frames with a blocking download instead of the side-stream ring")
 )
 

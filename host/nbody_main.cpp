@@ -322,7 +322,7 @@ int main(int argc, char** argv)
     cfg.G = gconst;
     cfg.precision = precision;
     cfg.collisions = nocollision ? 0 : 1;                    // main.go:24
-    cfg.num_devices = gpus;                                  // > 1: devices 0 .. gpus-1 (needs -nocollision)
+    cfg.num_devices = gpus;                                  // > 1: devices 0 .. gpus-1 (with collisions on: -tree only)
     // -asgo: the tree path with the Go program's own arithmetic (running cell centres tree.go:189-193, last
     // n mod 4 bodies unwalked main.go:134-148), for comparing a run with the reference number for number
     if (asgo && tree) cfg.reference_quirks = NBE_QUIRK_REF_COM | NBE_QUIRK_DROP_TAIL;

@@ -64,8 +64,9 @@ typedef struct {
  * synchronisation inside nbe_step).  Results are those of one GPU: bit for bit in tree mode, to the rounding of a
  * differently split source range in the direct sum.  nbe_upload, nbe_step, nbe_download, nbe_accel, nbe_energy,
  * nbe_stats, nbe_sync, nbe_tree_nodes, nbe_time_force_kernel and the frame stream work as with one GPU (reads come
- * from the first GPU); collisions, nbe_step_timed, nbe_set_stream, nbe_device_state and the nbe_shard_* calls are
- * refused with NBE_E_UNSUPPORTED.  The same ordinal may be listed more than once (several shards on one GPU). */
+ * from the first GPU; nbe_set_radius reaches every GPU).  Collisions work in tree mode (the GPUs share out the force pass and
+ * each runs the search, the merges and the update of all bodies), not in the direct sum; nbe_step_timed, nbe_set_stream,
+ * nbe_device_state and the nbe_shard_* calls are refused with NBE_E_UNSUPPORTED.  The same ordinal may be listed more than once (several shards on one GPU). */
 
 /* Who decides whether a cell is opened (tree.go:216-217, edge / distance > theta).
  *   NBE_WALK_PER_BODY   every body for itself, as the reference's recursion does: each body receives exactly the
@@ -111,6 +112,7 @@ typedef struct {
     uint64_t n;
     uint32_t elem_bytes;
     uint32_t reserved;
+    void *acc;              /* n elements of 4 reals: the accelerations nbe_shard_advance writes with collisions on */
 } nbe_device_state_t;
 
 /* Fills cfg with the reference's constants: tree off, fp32, G = 6.67408e-11 (physics.go:132),
@@ -182,7 +184,11 @@ int nbe_energy(nbe_engine *e, double *kinetic, double *potential, double momentu
  *                                 a host that owns several ranges can exchange one while the next is computed
  *   (caller all-gathers pos_mass_next and vel_next across engines)
  *   nbe_shard_commit              *_next become current
- * nbe_step is prepare + advance over all bodies + commit. */
+ * nbe_step is prepare + advance over all bodies + commit.
+ * With collisions on (tree mode only; NBE_E_UNSUPPORTED in the direct sum) nbe_shard_advance computes the accelerations of
+ * the range into `acc` (nbe_device_state) instead of updating, the caller all-gathers `acc`, and nbe_shard_commit runs
+ * the collision search, the merges and the update of all bodies on every engine alike (tree.go:245-281, main.go:151-167,
+ * physics.go:101-115, 153-162); radii must have been given to every engine. */
 int nbe_set_shard(nbe_engine *e, uint64_t first, uint64_t count);
 int nbe_shard_sort(nbe_engine *e);
 int nbe_shard_prepare(nbe_engine *e);

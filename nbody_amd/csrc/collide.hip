@@ -299,7 +299,8 @@ int collide_workspace_free(nbe_engine* e)
     CollWork& w = e->cw;
     void** ptrs[] = {(void**)&w.cnodes, (void**)&w.count, (void**)&w.offset, (void**)&w.pairs, (void**)&w.dead};
     for (void** p : ptrs) NBE_TRY(free_ptr(p));
-    w.cap = 0; w.pairs_cap = 0;
+    if (w.total_host) { NBE_HIP(hipHostFree(w.total_host)); w.total_host = nullptr; }
+    w.cap = 0; w.pairs_cap = 0; w.begun = false;
     return NBE_OK;
 }
 
@@ -316,6 +317,7 @@ int collide_workspace_reserve(nbe_engine* e)
     NBE_HIP(hipMemsetAsync(w.dead, 0, cap, e->stream));
     w.pairs_cap = 4096;
     NBE_HIP(hipMalloc((void**)&w.pairs, w.pairs_cap * sizeof(int2)));
+    NBE_HIP(hipHostMalloc((void**)&w.total_host, sizeof(uint32_t), hipHostMallocDefault));
     w.cap = cap;
     return NBE_OK;
 }
@@ -342,6 +344,41 @@ int collide_emit_nodes(nbe_engine* e)
     return NBE_OK;
 }
 
+// The counting search, the scan of the counts and the copy of their total to the host, all queued and not waited for:
+// a caller that drives several engines queues this on each of them before it finishes any.
+template <typename R4>
+static int collide_begin_t(nbe_engine* e, const void* force_pos)
+{
+    TreeWork& t = e->tw;
+    CollWork& w = e->cw;
+    const int n = (int)e->n;
+    const int cur = e->cur;
+    const double W = e->cfg.bound_width;
+    const double lox = e->cfg.bound_center[0] - 0.5 * W, loy = e->cfg.bound_center[1] - 0.5 * W,
+                 loz = e->cfg.bound_center[2] - 0.5 * W;
+    NBE_HIP(hipMemsetAsync(w.count, 0, ((size_t)n + 1) * 4, e->stream));
+    hipLaunchKernelGGL((collide_search_kernel<R4, false>), dim3(cdiv(n, 256)), dim3(256), 0, e->stream, w.cnodes, t.counters,
+                       t.keys[0], (const R4*)force_pos, e->radius[cur], e->orig[e->orig_cur], t.cellcnt, lox, loy, loz, W, w.count,
+                       w.offset, w.pairs);
+    NBE_HIP(hipGetLastError());
+    NBE_TRY(device_scan_u32(e, w.count, w.offset, (size_t)n + 1));
+    NBE_HIP(hipMemcpyAsync(w.total_host, w.offset + n, 4, hipMemcpyDeviceToHost, e->stream));
+    w.begun = true;
+    return NBE_OK;
+}
+
+int collide_begin(nbe_engine* e)
+{
+    if (e->cw.begun) return NBE_OK;
+    switch (e->cfg.precision) {
+    case NBE_PREC_F32: return collide_begin_t<float4>(e, e->posm[e->cur]);
+    case NBE_PREC_MIXED: return collide_begin_t<float4>(e, e->mirror[e->cur]);
+    case NBE_PREC_F64: return collide_begin_t<double4>(e, e->posm[e->cur]);
+    }
+    nbe_set_error("unknown precision %d", e->cfg.precision);
+    return NBE_E_INVALID;
+}
+
 template <typename R4, typename A4, typename A>
 static int collide_and_update_t(nbe_engine* e, const void* force_pos)
 {
@@ -355,15 +392,10 @@ static int collide_and_update_t(nbe_engine* e, const void* force_pos)
                  loz = e->cfg.bound_center[2] - 0.5 * W;
     const dim3 grid(cdiv(n, 256)), block(256);
 
-    NBE_HIP(hipMemsetAsync(w.count, 0, ((size_t)n + 1) * 4, e->stream));
-    hipLaunchKernelGGL((collide_search_kernel<R4, false>), grid, block, 0, e->stream, w.cnodes, t.counters, t.keys[0],
-                       (const R4*)force_pos, e->radius[cur], e->orig[e->orig_cur], t.cellcnt, lox, loy, loz, W, w.count, w.offset,
-                       w.pairs);
-    NBE_HIP(hipGetLastError());
-    NBE_TRY(device_scan_u32(e, w.count, w.offset, (size_t)n + 1));
-    uint32_t total = 0;
-    NBE_HIP(hipMemcpyAsync(&total, w.offset + n, 4, hipMemcpyDeviceToHost, e->stream));
+    NBE_TRY(collide_begin(e));
+    w.begun = false;
     NBE_HIP(hipStreamSynchronize(e->stream));
+    const uint32_t total = *w.total_host;
     e->stats.collision_pairs = total;
     if (total > 0) {
         if ((size_t)total > w.pairs_cap) {

@@ -254,6 +254,7 @@ static int upload_state(nbe_engine* e, size_t n, const double* pos, const double
     if (e->cfg.mode == NBE_MODE_TREE) NBE_TRY(tree_workspace_reserve(e));
     if (e->cfg.collisions) {
         NBE_TRY(collide_workspace_reserve(e));
+        e->cw.begun = false;
         NBE_TRY(collide_fill_radius(e, e->radius[0], 2.0));      // physics.go:20 defaultRadius
         NBE_HIP(hipMemsetAsync(e->cw.dead, 0, n, e->stream));
         if (e->cfg.mode == NBE_MODE_TREE) {
@@ -413,11 +414,25 @@ static int force_pass(nbe_engine* e, uint64_t t0, uint64_t t1, bool fused, bool 
     return direct_forces(e, e->cur, t0, t1, fused, e->cur ^ 1);
 }
 
+// Sharded stepping with collisions on (tree mode only): the force pass, which is nearly all of a step, is what the
+// engines share out; each computes the accelerations of its range into the acceleration buffer, the host exchanges
+// those, and nbe_shard_commit then runs the collision search, the merges and the update (collide.hip) over all bodies
+// on every engine alike, so that the replicated states stay identical.  The direct sum with collisions detects
+// touching pairs over all pairs and replays a merging step serially, which does not shard.
+static int check_sharded_collisions(const nbe_engine* e)
+{
+    if (e->cfg.collisions && e->cfg.mode != NBE_MODE_TREE) {
+        nbe_set_error("sharded stepping supports collisions in tree mode only; use nbe_step");
+        return NBE_E_UNSUPPORTED;
+    }
+    return NBE_OK;
+}
+
 extern "C" int nbe_shard_prepare(nbe_engine* e)
 {
     if (!e) { nbe_set_error("engine is NULL"); return NBE_E_INVALID; }
     NBE_NOT_MULTI(e, "nbe_shard_prepare");
-    if (e->cfg.collisions) { nbe_set_error("sharded stepping does not support collisions; use nbe_step"); return NBE_E_UNSUPPORTED; }
+    NBE_TRY(check_sharded_collisions(e));
     NBE_TRY(use_device(e));
     if (e->advance_pending) { nbe_set_error("nbe_shard_prepare before nbe_shard_commit"); return NBE_E_INVALID; }
     NBE_TRY(frame_stream_before_step(e));       // sends this step's frame once, however often prepare is called
@@ -430,10 +445,10 @@ extern "C" int nbe_shard_sort(nbe_engine* e)
 {
     if (!e) { nbe_set_error("engine is NULL"); return NBE_E_INVALID; }
     NBE_NOT_MULTI(e, "nbe_shard_sort");
-    if (e->cfg.collisions) { nbe_set_error("sharded stepping does not support collisions; use nbe_step"); return NBE_E_UNSUPPORTED; }
+    NBE_TRY(check_sharded_collisions(e));
     NBE_TRY(use_device(e));
     if (e->advance_pending) { nbe_set_error("nbe_shard_sort before nbe_shard_commit"); return NBE_E_INVALID; }
-    if (e->cfg.mode != NBE_MODE_TREE || e->prepared) return NBE_OK;
+    if (e->cfg.mode != NBE_MODE_TREE || e->prepared || e->cfg.collisions) return NBE_OK;   // (collisions: nothing runs ahead)
     return tree_sort_keys(e);
 }
 
@@ -441,7 +456,7 @@ extern "C" int nbe_shard_advance(nbe_engine* e)
 {
     if (!e) { nbe_set_error("engine is NULL"); return NBE_E_INVALID; }
     NBE_NOT_MULTI(e, "nbe_shard_advance");
-    if (e->cfg.collisions) { nbe_set_error("sharded stepping does not support collisions; use nbe_step"); return NBE_E_UNSUPPORTED; }
+    NBE_TRY(check_sharded_collisions(e));
     NBE_TRY(use_device(e));
     if (!e->prepared) { nbe_set_error("nbe_shard_advance without nbe_shard_prepare"); return NBE_E_INVALID; }
     if (e->advance_pending) { nbe_set_error("nbe_shard_advance called twice (advance several ranges with nbe_shard_advance_range)"); return NBE_E_INVALID; }
@@ -449,7 +464,7 @@ extern "C" int nbe_shard_advance(nbe_engine* e)
     uint64_t t1 = e->shard_set ? e->shard_first + e->shard_count : e->n;
     if (t1 > e->n) t1 = e->n;
     if (t0 > t1) t0 = t1;
-    NBE_TRY(force_pass(e, t0, t1, true));
+    NBE_TRY(force_pass(e, t0, t1, !e->cfg.collisions));      // collisions: accelerations only, the update follows the merges
     e->advance_pending = true;
     e->advance_parts++;
     return NBE_OK;
@@ -459,11 +474,11 @@ extern "C" int nbe_shard_advance_range(nbe_engine* e, uint64_t first, uint64_t c
 {
     if (!e) { nbe_set_error("engine is NULL"); return NBE_E_INVALID; }
     NBE_NOT_MULTI(e, "nbe_shard_advance_range");
-    if (e->cfg.collisions) { nbe_set_error("sharded stepping does not support collisions; use nbe_step"); return NBE_E_UNSUPPORTED; }
+    NBE_TRY(check_sharded_collisions(e));
     NBE_TRY(use_device(e));
     if (!e->prepared) { nbe_set_error("nbe_shard_advance_range without nbe_shard_prepare"); return NBE_E_INVALID; }
     if (first > e->n || count > e->n - first) { nbe_set_error("range [%llu, +%llu) outside 0..%zu", (unsigned long long)first, (unsigned long long)count, e->n); return NBE_E_INVALID; }
-    if (count > 0) NBE_TRY(force_pass(e, first, first + count, true));
+    if (count > 0) NBE_TRY(force_pass(e, first, first + count, !e->cfg.collisions));
     e->advance_pending = true;
     e->advance_parts += 2;                       // the ranges advanced are not (only) the shard set with nbe_set_shard
     return NBE_OK;
@@ -488,7 +503,10 @@ extern "C" int nbe_shard_commit(nbe_engine* e)
     if (!e->advance_pending) { nbe_set_error("nbe_shard_commit without nbe_shard_advance"); return NBE_E_INVALID; }
     NBE_TRY(use_device(e));
     const bool by_ranges = e->advance_parts > 1;      // nbe_shard_advance_range: rows of any range may have arrived from elsewhere
-    if (e->cfg.precision == NBE_PREC_MIXED && (by_ranges || (e->shard_set && e->shard_count < e->n))) {
+    if (e->cfg.collisions) {
+        // every engine holds all accelerations now: search, merge and update all bodies (writes the next-state buffers)
+        NBE_TRY(collide_and_update(e));
+    } else if (e->cfg.precision == NBE_PREC_MIXED && (by_ranges || (e->shard_set && e->shard_count < e->n))) {
         const int nxt = e->cur ^ 1;
         // with explicit ranges every row is converted (the engine's own rows come out as the update wrote them)
         hipLaunchKernelGGL(refresh_mirror_kernel, dim3(cdiv(e->n, 256)), dim3(256), 0, e->stream,
@@ -527,6 +545,7 @@ extern "C" int nbe_device_state(nbe_engine* e, nbe_device_state_t* out)
     out->n = e->n;
     out->elem_bytes = (uint32_t)e->elem;
     out->reserved = 0;
+    out->acc = e->acc;
     return NBE_OK;
 }
 
@@ -749,7 +768,11 @@ static int tree_nodes_impl(nbe_engine* e, double* out, size_t cap, size_t* count
     catch (const std::bad_alloc&) { nbe_set_error("out of host memory"); return NBE_E_NOMEM; }
 
 extern "C" int nbe_download(nbe_engine* e, double* pos, double* vel, double* mass, uint64_t* id, size_t* n_alive_out) { NBE_GUARDED(download_impl(NBE_FIRST(e), pos, vel, mass, id, n_alive_out)) }
-extern "C" int nbe_set_radius(nbe_engine* e, const double* radius) { NBE_GUARDED(set_radius_impl(NBE_FIRST(e), radius)) }
+extern "C" int nbe_set_radius(nbe_engine* e, const double* radius)
+{
+    if (e && e->multi) return multi_set_radius(e, radius);      // every GPU's engine holds the radii
+    NBE_GUARDED(set_radius_impl(e, radius))
+}
 extern "C" int nbe_get_radius(nbe_engine* e, double* radius, size_t* n_alive_out) { NBE_GUARDED(get_radius_impl(NBE_FIRST(e), radius, n_alive_out)) }
 extern "C" int nbe_accel(nbe_engine* e, double* acc_xyz, uint8_t* alive_out) { NBE_GUARDED(accel_impl(NBE_FIRST(e), acc_xyz, alive_out)) }
 extern "C" int nbe_tree_nodes(nbe_engine* e, double* out, size_t cap, size_t* count) { NBE_GUARDED(tree_nodes_impl(NBE_FIRST(e), out, cap, count)) }

@@ -101,6 +101,8 @@ struct CollWork {
     int2* pairs = nullptr;          // queue: (searching body, resident body) as sorted indices
     size_t pairs_cap = 0;
     uint8_t* dead = nullptr;        // per device slot: absorbed since the last sort
+    uint32_t* total_host = nullptr; // pinned: the number of queued pairs, read back between the counting and the filling search
+    bool begun = false;             // collide_begin has queued the counting search of this step
 };
 
 // Ring of pinned host buffers that carries frames from the GPU to a delivery thread.
@@ -193,6 +195,7 @@ void multi_destroy(nbe_engine* e);
 int multi_upload(nbe_engine* e, size_t n, const double* pos, const double* vel, const double* mass, const uint64_t* id);
 int multi_step(nbe_engine* e, int nsteps);
 int multi_sync(nbe_engine* e);
+int multi_set_radius(nbe_engine* e, const double* radius);
 nbe_engine* multi_first(nbe_engine* e);          // the engine of the first GPU (reads are served from it)
 // direct.hip
 int direct_forces(nbe_engine* e, int src_buf, uint64_t t0, uint64_t t1, bool fused, int dst_buf);
@@ -208,6 +211,7 @@ int collide_workspace_reserve(nbe_engine* e);
 int collide_workspace_free(nbe_engine* e);
 int collide_fill_radius(nbe_engine* e, double* dst, double value);
 int collide_emit_nodes(nbe_engine* e);          // after the build: geometry records for the collision search
+int collide_begin(nbe_engine* e);               // first half of collide_and_update: queues the counting search, does not wait
 int collide_and_update(nbe_engine* e);          // search + merge + update of the state in e->cur into e->cur^1
 // direct_collide.hip
 int direct_collide_reserve(nbe_engine* e);

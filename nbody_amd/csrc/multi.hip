@@ -64,7 +64,10 @@ int multi_create(const nbe_config* cfg, nbe_engine** out)
 {
     const int G = cfg->num_devices;
     if (G > 64) { nbe_set_error("num_devices %d: at most 64", G); return NBE_E_INVALID; }
-    if (cfg->collisions) { nbe_set_error("collisions are not supported with num_devices > 1"); return NBE_E_UNSUPPORTED; }
+    if (cfg->collisions && cfg->mode != NBE_MODE_TREE) {
+        nbe_set_error("collisions with num_devices > 1 need tree mode");
+        return NBE_E_UNSUPPORTED;
+    }
     nbe_engine* e = new (std::nothrow) nbe_engine();
     MultiState* m = new (std::nothrow) MultiState();
     if (!e || !m) { delete e; delete m; nbe_set_error("out of host memory"); return NBE_E_NOMEM; }
@@ -129,6 +132,12 @@ int multi_upload(nbe_engine* e, size_t n, const double* pos, const double* vel, 
     return NBE_OK;
 }
 
+int multi_set_radius(nbe_engine* e, const double* radius)
+{
+    for (nbe_engine* s : e->multi->subs) NBE_TRY(nbe_set_radius(s, radius));
+    return NBE_OK;
+}
+
 int multi_sync(nbe_engine* e)
 {
     for (nbe_engine* s : e->multi->subs) NBE_TRY(nbe_sync(s));
@@ -155,7 +164,10 @@ int multi_step(nbe_engine* e, int nsteps)
         // Only the positions gate the next step (keys and radix passes read nothing else).  In tree mode every GPU
         // therefore pulls the positions on its own stream, commits, starts the next step's key sort, and pulls the
         // velocities on a side stream meanwhile; its own stream takes the velocities' arrival in before anything else.
-        const bool overlap = e->cfg.mode == NBE_MODE_TREE;
+        // With collisions on, the advance left accelerations only: every GPU pulls the others' ranges of those, and
+        // the commit merges and updates all bodies on each GPU alike.
+        const bool collide = e->cfg.collisions != 0;
+        const bool overlap = e->cfg.mode == NBE_MODE_TREE && !collide;
         for (size_t s = 0; s < G; s++) {
             nbe_engine* dst = m->subs[s];
             NBE_HIP(hipSetDevice(m->devs[s]));
@@ -170,6 +182,10 @@ int multi_step(nbe_engine* e, int nsteps)
                 NBE_TRY(nbe_device_state(m->subs[r], &ss));
                 const size_t off = (size_t)m->first[r] * ds.elem_bytes, bytes = (size_t)m->count[r] * ds.elem_bytes;
                 NBE_HIP(hipStreamWaitEvent(dst->stream, m->advanced[r], 0));
+                if (collide) {
+                    NBE_HIP(hipMemcpyPeerAsync((char*)ds.acc + off, m->devs[s], (const char*)ss.acc + off, m->devs[r], bytes, dst->stream));
+                    continue;
+                }
                 NBE_HIP(hipMemcpyPeerAsync((char*)ds.pos_mass_next + off, m->devs[s], (const char*)ss.pos_mass_next + off, m->devs[r],
                                            bytes, dst->stream));
                 if (overlap) NBE_HIP(hipStreamWaitEvent(vstream, m->advanced[r], 0));
@@ -178,6 +194,12 @@ int multi_step(nbe_engine* e, int nsteps)
             }
             if (overlap) NBE_HIP(hipEventRecord(m->vel_done[s], vstream));
         }
+        // (the commit waits for the pair count of its GPU: queue every GPU's counting search first)
+        if (collide)
+            for (size_t r = 0; r < G; r++) {
+                NBE_HIP(hipSetDevice(m->devs[r]));
+                NBE_TRY(collide_begin(m->subs[r]));
+            }
         for (size_t r = 0; r < G; r++) {
             nbe_engine* sub = m->subs[r];
             NBE_TRY(nbe_shard_commit(sub));

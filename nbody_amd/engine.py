@@ -47,7 +47,8 @@ class Stats(C.Structure):
 
 class DeviceState(C.Structure):
     _fields_ = [("pos_mass", C.c_void_p), ("vel", C.c_void_p), ("pos_mass_next", C.c_void_p),
-                ("vel_next", C.c_void_p), ("n", C.c_uint64), ("elem_bytes", C.c_uint32), ("reserved", C.c_uint32)]
+                ("vel_next", C.c_void_p), ("n", C.c_uint64), ("elem_bytes", C.c_uint32), ("reserved", C.c_uint32),
+                ("acc", C.c_void_p)]
 
 
 class EngineError(RuntimeError):

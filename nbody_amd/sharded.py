@@ -53,6 +53,8 @@ class EngineShard:
         if use_current_stream:
             engine.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
         self._views = {}
+        # collisions (tree mode): advance leaves accelerations, the ranks exchange those, commit merges and updates
+        self.collisions = bool(engine.cfg.collisions)
 
     def set_shard(self, first, count):
         self.engine.set_shard(first, count)
@@ -73,14 +75,18 @@ class EngineShard:
     def commit(self):
         self.engine.shard_commit()
 
+    def _view(self, ptr, elem_bytes):
+        if ptr not in self._views:
+            self._views[ptr] = _wrap(ptr, self.n, elem_bytes, self.device)
+        return self._views[ptr]
+
     def next_state(self):
         ds = self.engine.device_state()
-        out = []
-        for ptr in (ds.pos_mass_next, ds.vel_next):
-            if ptr not in self._views:
-                self._views[ptr] = _wrap(ptr, self.n, ds.elem_bytes, self.device)
-            out.append(self._views[ptr])
-        return out
+        return [self._view(ptr, ds.elem_bytes) for ptr in (ds.pos_mass_next, ds.vel_next)]
+
+    def accelerations(self):
+        ds = self.engine.device_state()
+        return self._view(ds.acc, ds.elem_bytes)
 
 
 class ShardedStepper:
@@ -107,7 +113,10 @@ class ShardedStepper:
         self.even = self.per * self.world == self.n
         self.backend = dist.get_backend(group) if (self.world > 1 or always_gather) else None
         self._pad = {}
-        can_split = (hasattr(shard, "advance_range") and self.n > 0 and self.n % (2 * self.world * align) == 0
+        self.collisions = bool(getattr(shard, "collisions", False))
+        if self.collisions and split:
+            raise ValueError("split exchanges next-state rows; with collisions the ranks exchange accelerations")
+        can_split = (hasattr(shard, "advance_range") and not self.collisions and self.n > 0 and self.n % (2 * self.world * align) == 0
                      and (self.world > 1 or always_gather))
         if split is None:
             split = can_split and self.backend == "nccl"
@@ -201,6 +210,15 @@ class ShardedStepper:
             for _ in range(nsteps):
                 self._step_split()
             return
+        if self.collisions:
+            # the ranks share out the force pass; every rank then merges and updates all bodies alike (the search needs
+            # the tree of this step and the merges change neighbours, so nothing of the next step can run ahead)
+            for _ in range(nsteps):
+                self.shard.prepare()
+                self.shard.advance()
+                self._gather(self.shard.accelerations())
+                self.shard.commit()
+            return
         for _ in range(nsteps):
             self.shard.prepare()
             self.shard.advance()
@@ -226,6 +244,14 @@ class ShardedStepper:
         else:
             self.shard.advance()
         ev[2].record()
+        if self.collisions:
+            self._gather(self.shard.accelerations())
+            ev[3].record()
+            ev[4].record()
+            self.shard.commit()
+            torch.cuda.synchronize()
+            return {"build": ev[0].elapsed_time(ev[1]), "advance": ev[1].elapsed_time(ev[2]),
+                    "gather_accelerations": ev[2].elapsed_time(ev[3])}
         pos, vel = self.shard.next_state()
         if self.split:
             for k in range(2):

@@ -22,8 +22,12 @@ from nbody_amd.sharded import ShardedStepper  # noqa: E402
 class OracleShard:
     """Same methods as nbody_amd.sharded.EngineShard, state in CPU tensors, forces from the CPU oracle."""
 
-    def __init__(self, bodies, mode, theta, dt):
+    def __init__(self, bodies, mode, theta, dt, collisions=False):
         from oracle import oracle as O
+        # collisions: the calling sequence of an engine with collisions on (advance leaves accelerations, the ranks
+        # exchange those, commit updates every body); the stand-in's bodies never touch, so no merge happens
+        self.collisions = collisions
+        self.acc = torch.zeros(len(bodies), 4, dtype=torch.float64)
         self.O = O
         self.n = len(bodies)
         self.mode, self.theta, self.dt = mode, theta, dt
@@ -45,6 +49,9 @@ class OracleShard:
         else:
             f = self.O.direct_rows(mass, pos, nthreads=2)
         s = slice(self.first, self.first + self.count)
+        if self.collisions:
+            self.acc[s, :3] = torch.from_numpy(f[s] / mass[s, None])
+            return
         v = vel[s] + f[s] / mass[s, None] * self.dt
         p = pos[s] + v * self.dt
         self.nxt[0][s, :3] = torch.from_numpy(p); self.nxt[0][s, 3] = self.cur[0][s, 3]
@@ -59,7 +66,15 @@ class OracleShard:
     def next_state(self):
         return self.nxt
 
+    def accelerations(self):
+        return self.acc
+
     def commit(self):
+        if self.collisions:
+            v = self.cur[1][:, :3] + self.acc[:, :3] * self.dt
+            self.nxt[1][:, :3] = v
+            self.nxt[0][:, :3] = self.cur[0][:, :3] + v * self.dt
+            self.nxt[0][:, 3] = self.cur[0][:, 3]
         self.cur, self.nxt = self.nxt, self.cur
 
 
@@ -69,22 +84,35 @@ def main():
     dist.init_process_group("gloo", rank=rank, world_size=world)
     bodies = physics.makebodies(n - 2, seed=11)
     if kind == "oracle":
-        shard = OracleShard(bodies, mode, 0.5, 3600.0)
+        shard = OracleShard(bodies, mode, 0.5, 3600.0, collisions="collide" in sys.argv[6:])
         # the CPU stand-in has no wavefronts to align the ranges with; "split" as a seventh argument rehearses the
         # two-ranges-per-rank exchange
         stepper = ShardedStepper(shard, align=1, split="split" in sys.argv[6:])
         stepper.step(nsteps)
         pos = shard.cur[0][:, :3].numpy(); vel = shard.cur[1][:, :3].numpy()
+        more = {}
     else:
         from nbody_amd import Engine
         from nbody_amd.sharded import EngineShard
         prec = sys.argv[6]
-        eng = Engine(mode=mode, precision=prec, theta=0.5)
+        extra = {}
+        if "collide" in sys.argv[7:]:
+            # a crowd that merges (the scene of tests/test_gpu_collide.py)
+            rng = np.random.default_rng(5)
+            bodies = physics.Bodies(rng.uniform(-60.0, 60.0, (n, 3)), rng.normal(0, 1e-3, (n, 3)), np.abs(rng.normal(1e3, 500, n)) + 1)
+            extra = dict(collisions=True, dt=100.0)
+        eng = Engine(mode=mode, precision=prec, theta=0.5, **extra)
         eng.upload(bodies.pos, bodies.vel, bodies.mass)
+        if extra:
+            eng.set_radius(np.random.default_rng(6).uniform(0.5, 3.0, n))
         stepper = ShardedStepper(EngineShard(eng), split="split" in sys.argv[7:])
         stepper.step(nsteps)
-        pos, vel, _, _ = eng.download()
-    np.savez(f"{out_prefix}.rank{rank}.npz", pos=pos, vel=vel, first=stepper.first, count=stepper.count)
+        pos, vel, mass, ids = eng.download()
+        more = dict(mass=mass, ids=ids)
+        if extra:
+            more["radius"] = eng.get_radius()
+            more["merges"] = eng.stats().merges
+    np.savez(f"{out_prefix}.rank{rank}.npz", pos=pos, vel=vel, first=stepper.first, count=stepper.count, **more)
     dist.barrier()
     dist.destroy_process_group()
 

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layouts_match_header_sizes():
     assert C.sizeof(E.Config) == 2 * 4 + 4 * 8 + 3 * 8 + 8 + 4 * 4 + 4 + 4 + 8      # ... num_devices, padding, device_ids
     assert C.sizeof(E.Stats) == 8 * 8 + 4 * 4
-    assert C.sizeof(E.DeviceState) == 4 * 8 + 8 + 4 + 4
+    assert C.sizeof(E.DeviceState) == 4 * 8 + 8 + 4 + 4 + 8
 
 
 def test_default_config_holds_reference_constants():

@@ -204,13 +204,15 @@ def test_accel_and_energy_after_merges(gpu):
 
 def test_unsupported_combinations_fail_loudly(gpu):
     pos, vel, mass, rad = crowd(100, 20.0, 1)
-    with Engine(mode="tree", collisions=True) as e:
+    with Engine(mode="direct", collisions=True) as e:
         e.upload(pos, vel, mass)
         e.set_shard(0, 50)
         with pytest.raises(EngineError, match="sharded"):
             e.shard_prepare()
         with pytest.raises(EngineError, match="negative"):
             e.set_radius(-rad)
+    with pytest.raises(EngineError, match="tree mode"):
+        Engine(mode="direct", collisions=True, devices=[0, 0])
     with Engine(mode="tree") as e:
         e.upload(pos, vel, mass)
         with pytest.raises(EngineError, match="collisions on"):
@@ -345,3 +347,75 @@ def test_engine_against_the_collision_golden_vectors(gpu, name, mode):
     assert np.abs(r - g[key + "_radius"][live]).max() <= 1e-13 * r.max()
     assert np.abs(p - g[key + "_pos"][live]).max() <= 1e-11 * np.abs(p).max()
     assert np.abs(v - g[key + "_vel"][live]).max() <= 1e-9 * np.abs(v).max()
+
+
+# ---- collisions with the force pass shared out (tree mode) ---------------------------------------------------------
+@pytest.mark.parametrize("precision", ["f64", "mixed", "f32"])
+def test_force_pass_in_ranges_then_one_merge(gpu, precision):
+    """nbe_shard_advance_range with collisions on fills the accelerations range by range; nbe_shard_commit then
+    searches, merges and updates all bodies: the same state as nbe_step, bit for bit, on a scene that merges."""
+    pos, vel, mass, rad = crowd(3000, 70.0, 21)
+    want = run_engine(pos, vel, mass, rad, 4, precision=precision, theta=0.8, dt=100.0)
+    with Engine(mode="tree", precision=precision, collisions=True, theta=0.8, dt=100.0) as e:
+        e.upload(pos, vel, mass)
+        e.set_radius(rad)
+        per_step = []
+        for s in range(4):
+            e.shard_prepare()
+            if s % 2:
+                e.shard_advance()
+            else:
+                # (ranges start at multiples of 256: mixed precision rounds by the wavefront's 64 bodies)
+                for first, count in ((0, 1024), (1024, 1024), (2048, 952)):
+                    e.shard_advance_range(first, count)
+            e.shard_commit()
+            st = e.stats()
+            per_step.append((int(st.collision_pairs), int(st.merges), int(st.n_alive)))
+        got = e.download() + (e.get_radius(), per_step)
+    assert want[5][-1][1] > 20 and got[5] == want[5]
+    for a, w in zip(got[:5], want[:5]):
+        assert np.array_equal(a, w)
+
+
+@pytest.mark.parametrize("precision", ["f64", "mixed", "f32"])
+def test_several_shards_behind_one_handle_with_collisions(gpu, precision):
+    """Engine(devices=[0, 0, 0], collisions=True): the shards share out the force pass, pull each other's
+    accelerations, and each merges and updates all bodies alike; the frames (first shard) carry radii and leave out
+    the absorbed.  Equal to a one-shard engine bit for bit."""
+    pos, vel, mass, rad = crowd(5000, 90.0, 22)
+    want = run_engine(pos, vel, mass, rad, 6, precision=precision, theta=0.7, dt=100.0)
+    frames = []
+    with Engine(mode="tree", precision=precision, collisions=True, theta=0.7, dt=100.0, devices=[0, 0, 0]) as e:
+        e.upload(pos, vel, mass)
+        e.set_radius(rad)
+        e.frame_stream_begin(lambda f, xyzm, ids, radius: frames.append((f, len(ids), radius.copy())), every=1, slots=2)
+        per_step = []
+        for _ in range(6):
+            e.step(1)
+            st = e.stats()
+            per_step.append((int(st.collision_pairs), int(st.merges), int(st.n_alive)))
+        e.frame_stream_end()
+        got = e.download() + (e.get_radius(), per_step)
+    assert want[5][-1][1] > 30 and got[5] == want[5]
+    for a, w in zip(got[:5], want[:5]):
+        assert np.array_equal(a, w)
+    assert [f for f, _, _ in frames] == list(range(6))
+    assert [k for _, k, _ in frames] == [len(mass)] + [alive for _, _, alive in want[5][:5]]
+    assert np.array_equal(np.sort(frames[0][2]), np.sort(rad.astype(np.float32)))
+
+
+def test_two_ranks_share_the_force_pass_with_collisions(gpu, tmp_path):
+    """world_size 2 over gloo, both ranks on cuda:0, collisions on: the ranks all-gather accelerations, and both hold
+    the state a single engine reaches."""
+    from tests.test_sharded_gloo import run_ranks
+    n = 3001
+    res = run_ranks(tmp_path, 2, ["tree", str(n), "4", "gpu", "f64", "collide"], timeout=240)
+    rng = np.random.default_rng(5)
+    pos, vel, mass = rng.uniform(-60.0, 60.0, (n, 3)), rng.normal(0, 1e-3, (n, 3)), np.abs(rng.normal(1e3, 500, n)) + 1
+    rad = np.random.default_rng(6).uniform(0.5, 3.0, n)
+    p, v, m, ids, r, per_step = run_engine(pos, vel, mass, rad, 4, theta=0.5, dt=100.0)
+    assert per_step[-1][1] > 20
+    for k in range(2):
+        assert int(res[k]["merges"]) == per_step[-1][1]
+        for name, w in (("pos", p), ("vel", v), ("mass", m), ("ids", ids), ("radius", r)):
+            assert np.array_equal(res[k][name], w), (k, name)

@@ -65,11 +65,13 @@ def test_shard_ranges_cover_everything_once():
 
 
 @pytest.mark.parametrize("mode,n,split", [("direct", 64, False), ("direct", 63, False), ("tree", 64, False), ("tree", 61, False),
-                                         ("direct", 64, True), ("tree", 64, True)])
+                                         ("direct", 64, True), ("tree", 64, True), ("tree", 61, "collide")])
 def test_two_ranks_reproduce_single_process(tmp_path, mode, n, split):
     """split: every rank owns a slice of each half of the body order and exchanges the halves one after the other (the
-    arrangement that lets the first exchange run beside the second force pass on RCCL)."""
-    res = run_ranks(tmp_path, 2, [mode, str(n), "3", "oracle", "-"] + (["split"] if split else []))
+    arrangement that lets the first exchange run beside the second force pass on RCCL).  "collide": the calling
+    sequence of an engine with collisions on, where the ranks exchange accelerations and every rank updates all bodies."""
+    res = run_ranks(tmp_path, 2, [mode, str(n), "3", "oracle", "-"] + ([split if isinstance(split, str) else "split"] if split else []))
+    split = split is True
     assert np.array_equal(res[0]["pos"], res[1]["pos"]) and np.array_equal(res[0]["vel"], res[1]["vel"])
     if split:
         assert int(res[0]["first"]) == 0 and int(res[0]["count"]) == n // 4 and int(res[1]["first"]) == n // 4
