@@ -53,6 +53,7 @@ typedef struct {
     int reference_quirks;   /* tree mode: bit set of NBE_QUIRK_*; 0 = physically meant behaviour */
     int walk_criterion;     /* tree mode: NBE_WALK_PER_BODY (the reference's test, default) or NBE_WALK_PER_WAVE */
     int num_devices;        /* 0 or 1: one GPU, `device`.  G > 1: the engine drives G GPUs from this process, see below */
+    int cell_sums;          /* tree mode, fp32 node records: NBE_SUMS_PREFIX (default) or NBE_SUMS_TREE, see below */
     const int *device_ids;  /* num_devices HIP device ordinals (copied by nbe_create); NULL = devices 0 .. G-1 */
 } nbe_config;
 
@@ -67,6 +68,15 @@ typedef struct {
  * from the first GPU; nbe_set_radius reaches every GPU).  Collisions work in tree mode (the GPUs share out the force pass and
  * each runs the search, the merges and the update of all bodies), not in the direct sum; nbe_step_timed, nbe_set_stream,
  * nbe_device_state and the nbe_shard_* calls are refused with NBE_E_UNSUPPORTED.  The same ordinal may be listed more than once (several shards on one GPU). */
+
+/* How a cell's mass and centre of mass are summed (fp64 either way).
+ *   NBE_SUMS_PREFIX   differences of prefix sums over the Morton-sorted bodies: three launches, the fastest, and the
+ *                     rounding of a cell's sums depends on everything sorted before it.  fp32 node records only
+ *                     (the error stays below their rounding); fp64 node records always use NBE_SUMS_TREE.
+ *   NBE_SUMS_TREE     every cell adds up its children in octant order, bodies as they stand: a cell's sums depend on
+ *                     nothing outside it, so trees built from any partition of the bodies carry the same bits.  This is
+ *                     what the key-range-distributed build (nbe_dist_*) uses. */
+enum { NBE_SUMS_PREFIX = 0, NBE_SUMS_TREE = 1 };
 
 /* Who decides whether a cell is opened (tree.go:216-217, edge / distance > theta).
  *   NBE_WALK_PER_BODY   every body for itself, as the reference's recursion does: each body receives exactly the
@@ -196,6 +206,77 @@ int nbe_shard_advance(nbe_engine *e);
 int nbe_shard_advance_range(nbe_engine *e, uint64_t first, uint64_t count);
 int nbe_shard_commit(nbe_engine *e);
 int nbe_device_state(nbe_engine *e, nbe_device_state_t *out);
+
+/* ---- key-range-distributed tree (one engine per GPU, every body resident on ONE engine) ----
+ * The sharded stepping above replicates the bodies and the tree build on every engine; this path distributes both, for
+ * runs where the replicated sort and build would cap the scaling.  It still computes what main.go:130-149 computes: every
+ * body walks the one octree of all bodies (tree.go:202-240); the octree is only never assembled in one place.
+ *   * Rank r owns the bodies whose Morton key lies in [split[r], split[r+1]) and holds nothing else.  After every update
+ *     the bodies that crossed a splitter move to their new owner (nbe_dist_classify / the caller's all-to-all of the
+ *     migration records / nbe_dist_receive).
+ *   * Every rank sorts its own bodies and builds the octree over them (nbe_dist_build).  A subtree whose cell lies
+ *     wholly inside the rank's key range is exactly that subtree of the global octree (a "fragment"); the few cells
+ *     above the fragments, which span ranks, are rebuilt on every rank from the fragments' roots (key, depth, fp64
+ *     sums), all-gathered by the caller.  Cell sums are NBE_SUMS_TREE, so they carry the bits of a one-engine build.
+ *   * For every other rank q, nbe_dist_export prunes each fragment to the nodes some body of q could visit (cells whose
+ *     opening test no point of q's bounding box can pass are cut below), in pre-order with skip pointers; the caller
+ *     moves these records (all-to-all), and nbe_dist_assemble lays out the rank's own fragments, the imported ones and
+ *     the spanning cells as one pre-order node array.  The walk kernel then runs on it unchanged (nbe_dist_advance):
+ *     every body visits exactly the nodes it visits in the one-engine tree, in the same order, so fp32 and fp64 runs
+ *     equal a one-engine run with cell_sums = NBE_SUMS_TREE bit for bit (NBE_PREC_MIXED to rounding: its partial sums
+ *     are flushed by wavefront, and the wavefronts hold other bodies).
+ * Tree mode, collisions off, NBE_WALK_PER_BODY, no reference_quirks.  nbe_step and the nbe_shard_* calls are refused on
+ * such an engine. */
+typedef struct {
+    uint64_t key;           /* Morton key of the fragment's first body */
+    int32_t level;          /* depth of the fragment's root cell; 255: the fragment is one body */
+    int32_t start;          /* pre-order index of the root in the owner's node array */
+    int32_t nodes;          /* nodes of the subtree */
+    int32_t reserved;
+    double sum[4];          /* fp64 mass, sum m*x, sum m*y, sum m*z of the fragment */
+} nbe_fragment_t;
+
+typedef struct {
+    void *outbox, *inbox;   /* migration records, `slots` of them each; a record is 2 * elem_bytes (position+mass, velocity+index) */
+    void *export_nodes;     /* what nbe_dist_export wrote: node records for the other ranks, destination after destination */
+    void *import_nodes;     /* where the caller puts the records exported to this rank, source rank after source rank */
+    uint64_t slots, export_cap, import_cap;   /* capacities in records / nodes */
+    uint32_t record_bytes, node_bytes;
+} nbe_dist_buffers_t;
+
+#define NBE_DIST_MAX_FRAGMENTS 2048
+
+/* Replaces nbe_upload: the `n` bodies this rank starts with (any subset of the run's bodies; they are redistributed by
+ * the first nbe_dist_classify), in an engine with room for `capacity` >= n bodies.  `first_index` numbers them:
+ * body i gets the run-wide index first_index + i, which travels with it and comes back from nbe_dist_download. */
+int nbe_dist_upload(nbe_engine *e, int rank, int world, size_t capacity, size_t n, const double *pos_xyz,
+                    const double *vel_xyz, const double *mass, uint64_t first_index);
+/* Up to max_samples evenly spaced keys of the rank's bodies in sorted order (for choosing splitters); *n_live = bodies
+ * inside the bound. */
+int nbe_dist_sample_keys(nbe_engine *e, size_t max_samples, uint64_t *keys_out, size_t *count, size_t *n_live);
+/* split[0] = 0 <= split[1] <= ... <= split[world] = 2^63: rank r owns keys in [split[r], split[r+1]). */
+int nbe_dist_set_splitters(nbe_engine *e, const uint64_t *split);
+int nbe_dist_buffers(nbe_engine *e, nbe_dist_buffers_t *out);
+/* Packs the bodies that belong to other ranks into the outbox (those for rank d start at record
+ * send_counts[0] + ... + send_counts[d-1]) and removes them here.  Synchronises. */
+int nbe_dist_classify(nbe_engine *e, uint32_t *send_counts);
+/* Takes over the first k records of the inbox. */
+int nbe_dist_receive(nbe_engine *e, size_t k);
+/* Sorts the rank's bodies, builds its tree and lists its fragments in key order (at most `max`); aabb = min x,y,z and
+ * max x,y,z of its bodies.  Synchronises. */
+int nbe_dist_build(nbe_engine *e, nbe_fragment_t *frags, int max, int *count, double aabb[6], uint64_t *n_live);
+/* all_frags: the fragments of rank 0, then rank 1, ... (frag_counts[r] each); aabbs: world x 6.  Writes the pruned
+ * fragments for every other rank into export_nodes; export_offsets[d] .. export_offsets[d+1] are the nodes for rank d,
+ * export_sizes[d * frag_counts[rank] + f] the nodes of this rank's fragment f in there.  Synchronises. */
+int nbe_dist_export(nbe_engine *e, const nbe_fragment_t *all_frags, const int *frag_counts, const double *aabbs,
+                    int32_t *export_sizes, uint64_t *export_offsets);
+/* import_sizes: for every rank r in turn, the sizes its frag_counts[r] fragments have in its export to this rank (this
+ * rank's own entries are ignored); import_offsets[r]: where rank r's export starts in import_nodes, in nodes. */
+int nbe_dist_assemble(nbe_engine *e, const int32_t *import_sizes, const uint64_t *import_offsets);
+/* Force pass over the assembled node array + fused update of the rank's bodies (main.go:130-149, 171-177). */
+int nbe_dist_advance(nbe_engine *e);
+/* The rank's live bodies: run-wide index, position, velocity, mass (any pointer may be NULL). */
+int nbe_dist_download(nbe_engine *e, uint64_t *index, double *pos_xyz, double *vel_xyz, double *mass, size_t *count);
 
 /* Run the engine's work on a caller-owned hipStream_t instead of the engine's own non-blocking stream, so
  * that it is ordered with the caller's other work (copies, collectives).  NULL selects HIP's default (null)

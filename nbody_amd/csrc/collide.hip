@@ -18,7 +18,6 @@
 #include "kernels_common.h"
 #include "tree_keys.h"
 
-int device_scan_u32(nbe_engine* e, const uint32_t* in, uint32_t* out, size_t len);   // tree_build.hip
 
 struct Cell { double cx, cy, cz, w; };
 
@@ -377,6 +376,16 @@ int collide_begin(nbe_engine* e)
     }
     nbe_set_error("unknown precision %d", e->cfg.precision);
     return NBE_E_INVALID;
+}
+
+int collide_emit_geometry(nbe_engine* e)
+{
+    TreeWork& t = e->tw;
+    const int n = (int)e->n;
+    hipLaunchKernelGGL(emit_cnodes_kernel, dim3(cdiv(2 * (size_t)n, 256)), dim3(256), 0, e->stream, n, t.counters, t.keys[0],
+                       t.bt_first, t.bt_last, t.bt_parent, t.bt_level, t.lvlmask, t.cellcnt, e->cw.cnodes);
+    NBE_HIP(hipGetLastError());
+    return NBE_OK;
 }
 
 template <typename R4, typename A4, typename A>

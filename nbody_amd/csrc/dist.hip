@@ -1,0 +1,950 @@
+// Key-range-distributed Barnes-Hut tree: every body is resident on one engine (rank) only.
+//
+// The reference walks one octree of all bodies with a fan-out over workers (main.go:130-149, tree.go:202-240).  Here
+// the octree is never assembled in one place: rank r owns the bodies whose Morton key lies in [split[r], split[r+1]),
+// builds the octree of those, and the ranks exchange just enough of their trees for every body to find, on its own
+// rank, every node its walk of the global octree would visit:
+//   * a subtree whose cell lies wholly inside the rank's key range is that very subtree of the global octree (all
+//     bodies of the cell are here): a "fragment".  Fragments are found from the geometry records of the nodes;
+//   * the cells above the fragments span ranks.  There are few of them (the ancestors of the splitters); every rank
+//     rebuilds them from the all-gathered fragment roots (plan_layout, on the host), adding the children's fp64 sums in
+//     octant order exactly as cell_mass_kernel does, so these cells carry the bits of a one-engine build;
+//   * for another rank q a fragment is pruned to what q can need: a cell whose opening test (tree.go:216-217) no point
+//     of q's bounding box can pass is accepted by every body of q, so nothing below it is ever visited from there.
+//     The pruned fragments keep pre-order and get new skip pointers (export_* kernels);
+//   * own fragments, imported ones and the spanning cells are laid out as one pre-order node array (assemble_kernel),
+//     on which the unchanged walk kernel runs.
+// Bodies that cross a splitter are handed to their new owner between steps (classify / pack / append kernels).
+// The host moves the bytes between ranks (torch.distributed all-to-all / all-gather in nbody_amd/disttree.py); this file
+// holds everything else.
+#include "engine_internal.h"
+#include "kernels_common.h"
+#include "tree_keys.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <new>
+#include <vector>
+
+struct Segment {          // one fragment in the assembled node array
+    int dst;              // first index there
+    int count;            // nodes
+    int src;              // first index in the source array (own nodes / import buffer)
+    int rebase;           // added to every skip pointer: dst - (the index the source's skips are relative to)
+    int remote;           // 0: own node array, 1: import buffer
+};
+
+struct TopCell {          // a cell that spans ranks
+    int dst, skip, level;
+    double sum[4];
+};
+
+struct DistState {
+    int rank = 0, world = 1;
+    size_t cap = 0;                     // body slots of this engine (== e->n)
+    size_t live_hi = 0;                 // slots [0, live_hi) may hold bodies, everything behind is free
+    std::vector<uint64_t> split;        // world + 1
+    uint64_t* d_split = nullptr;
+    uint32_t* d_counts = nullptr;       // [0, world) bodies leaving per destination, [world, 2 world) pack cursors, [2 world] freed slots
+    uint32_t* h_counts = nullptr;       // pinned copy
+    void* outbox = nullptr;
+    void* inbox = nullptr;
+    uint32_t* free_slots = nullptr;     // slots vacated by the last classify
+    uint32_t n_free = 0;
+    bool classified = false, built = false, exported = false, assembled = false;
+    // fragments of the last build
+    nbe_fragment_t* d_frags = nullptr;
+    int* d_nfrag = nullptr;             // [0] count, [1] overflow flag of the export buffer
+    nbe_fragment_t* h_frags = nullptr;  // pinned
+    int* h_small = nullptr;             // pinned scratch: counters and sizes
+    double* d_aabb = nullptr;           // partial boxes [1024][6] then the final [6]
+    double* h_aabb = nullptr;           // pinned [6]
+    std::vector<nbe_fragment_t> my_frags;          // sorted by key
+    std::vector<nbe_fragment_t> all_frags;         // rank after rank
+    std::vector<int> frag_counts;
+    // export
+    uint32_t* x_diff = nullptr;         // 2 cap + 2 each
+    uint32_t* x_cover = nullptr;
+    uint32_t* x_flag = nullptr;
+    uint32_t* x_index = nullptr;
+    void* export_nodes = nullptr;
+    size_t export_cap = 0;
+    unsigned long long* d_export_base = nullptr;   // world + 1 running node offsets
+    int* d_export_sizes = nullptr;      // world x NBE_DIST_MAX_FRAGMENTS
+    double* d_boxes = nullptr;          // world x 6
+    // import + assembled array
+    void* import_nodes = nullptr;
+    size_t import_cap = 0;
+    void* let_nodes = nullptr;
+    size_t let_cap = 0;
+    int* let_counters = nullptr;        // [0] live bodies of this rank, [1] nodes of the assembled array
+    Segment* d_segments = nullptr;
+    TopCell* d_top = nullptr;
+    size_t seg_cap = 0, top_cap = 0;
+};
+
+static int dfree(void** p)
+{
+    if (*p) { NBE_HIP(hipFree(*p)); *p = nullptr; }
+    return NBE_OK;
+}
+
+void dist_destroy(nbe_engine* e)
+{
+    DistState* d = e->dist;
+    if (!d) return;
+    void** dev[] = {(void**)&d->d_split, (void**)&d->d_counts, &d->outbox, &d->inbox, (void**)&d->free_slots, (void**)&d->d_frags,
+                    (void**)&d->d_nfrag, (void**)&d->d_aabb, (void**)&d->x_diff, (void**)&d->x_cover, (void**)&d->x_flag,
+                    (void**)&d->x_index, &d->export_nodes, (void**)&d->d_export_base, (void**)&d->d_export_sizes,
+                    (void**)&d->d_boxes, &d->import_nodes, &d->let_nodes, (void**)&d->let_counters, (void**)&d->d_segments,
+                    (void**)&d->d_top};
+    for (void** p : dev) (void)dfree(p);
+    void* host[] = {d->h_counts, d->h_frags, d->h_small, d->h_aabb};
+    for (void* p : host)
+        if (p) (void)hipHostFree(p);
+    delete d;
+    e->dist = nullptr;
+}
+
+static int check_dist(nbe_engine* e, const char* name)
+{
+    if (!e) { nbe_set_error("engine is NULL"); return NBE_E_INVALID; }
+    if (!e->dist) { nbe_set_error("%s needs an engine set up with nbe_dist_upload", name); return NBE_E_INVALID; }
+    NBE_HIP(hipSetDevice(e->cfg.device));
+    return NBE_OK;
+}
+
+static void bound_lo(const nbe_engine* e, double lo[3], double* W)
+{
+    *W = e->cfg.bound_width;
+    for (int c = 0; c < 3; c++) lo[c] = e->cfg.bound_center[c] - 0.5 * *W;
+}
+
+// ---- setting up ------------------------------------------------------------------------------------------------
+// Run-wide body indices: what `orig` holds on a distributed engine (the plain engine keeps upload indices there).
+__global__ __launch_bounds__(256) void add_index_kernel(uint32_t* __restrict__ orig0, uint32_t* __restrict__ orig1, int n, uint32_t first)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    orig0[i] += first;
+    orig1[i] += first;
+}
+
+extern "C" int nbe_dist_upload(nbe_engine* e, int rank, int world, size_t capacity, size_t n, const double* pos, const double* vel,
+                               const double* mass, uint64_t first_index)
+{
+    if (!e) { nbe_set_error("engine is NULL"); return NBE_E_INVALID; }
+    if (e->multi) { nbe_set_error("nbe_dist_upload on an engine with num_devices > 1"); return NBE_E_UNSUPPORTED; }
+    if (e->cfg.mode != NBE_MODE_TREE || e->cfg.collisions || e->cfg.reference_quirks || e->cfg.walk_criterion != NBE_WALK_PER_BODY) {
+        nbe_set_error("the distributed tree needs tree mode, collisions off, the per-body criterion and no reference_quirks");
+        return NBE_E_UNSUPPORTED;
+    }
+    if (world < 1 || world > 4096 || rank < 0 || rank >= world) { nbe_set_error("bad rank %d of %d", rank, world); return NBE_E_INVALID; }
+    if (capacity < n || capacity == 0) { nbe_set_error("capacity %zu < n %zu (or 0)", capacity, n); return NBE_E_INVALID; }
+    if (capacity > (1ull << 26) || first_index + n > 0xffffffffull) { nbe_set_error("at most 2^26 bodies per rank and 2^32 in all"); return NBE_E_UNSUPPORTED; }
+    if (n > 0 && (!pos || !vel || !mass)) { nbe_set_error("nbe_dist_upload: NULL array"); return NBE_E_INVALID; }
+    for (size_t i = 0; i < n; i++)
+        if (!(mass[i] >= 0.0)) { nbe_set_error("mass[%zu] is negative or NaN", i); return NBE_E_INVALID; }
+    NBE_HIP(hipSetDevice(e->cfg.device));
+    dist_destroy(e);
+    DistState* d = new (std::nothrow) DistState();
+    if (!d) { nbe_set_error("out of host memory"); return NBE_E_NOMEM; }
+    e->dist = d;
+    e->cfg.cell_sums = NBE_SUMS_TREE;
+    e->tw.cap = 0;                                   // the tree workspace is laid out anew (sums by tree, scans over nodes)
+    d->rank = rank; d->world = world; d->cap = capacity; d->live_hi = n;
+    // free slots hold massless bodies parked outside the bound: the sort sends them behind the live ones
+    double lo[3], W;
+    bound_lo(e, lo, &W);
+    int rc = NBE_OK;
+    try {
+        std::vector<double> hp(3 * capacity), hv(3 * capacity, 0.0), hm(capacity, 0.0);
+        if (n) { memcpy(hp.data(), pos, 3 * n * sizeof(double)); memcpy(hv.data(), vel, 3 * n * sizeof(double)); memcpy(hm.data(), mass, n * sizeof(double)); }
+        for (size_t i = n; i < capacity; i++)
+            for (int c = 0; c < 3; c++) hp[3 * i + c] = lo[c] + 2.0 * W;
+        rc = engine_upload_state(e, capacity, hp.data(), hv.data(), hm.data(), nullptr);
+    } catch (const std::bad_alloc&) { nbe_set_error("out of host memory"); rc = NBE_E_NOMEM; }
+    if (rc != NBE_OK) return rc;
+    e->small_max = 0;                                // one code path for every size
+    hipLaunchKernelGGL(add_index_kernel, dim3(cdiv(capacity, 256)), dim3(256), 0, e->stream, e->orig[0], e->orig[1], (int)capacity,
+                       (uint32_t)first_index);
+    NBE_HIP(hipGetLastError());
+    NBE_TRY(collide_workspace_reserve(e));           // the geometry records of the nodes live in the collision workspace
+    const size_t W2 = (size_t)world;
+    const size_t nodes2 = 2 * capacity + 2;
+    const size_t node_bytes = e->force64 ? sizeof(NodeD) : sizeof(NodeF);
+    NBE_HIP(hipMalloc((void**)&d->d_split, (W2 + 1) * 8));
+    NBE_HIP(hipMalloc((void**)&d->d_counts, (2 * W2 + 1) * 4));
+    NBE_HIP(hipHostMalloc((void**)&d->h_counts, (2 * W2 + 1) * 4, hipHostMallocDefault));
+    NBE_HIP(hipMalloc(&d->outbox, capacity * 2 * e->elem));
+    NBE_HIP(hipMalloc(&d->inbox, capacity * 2 * e->elem));
+    NBE_HIP(hipMalloc((void**)&d->free_slots, capacity * 4));
+    NBE_HIP(hipMalloc((void**)&d->d_frags, NBE_DIST_MAX_FRAGMENTS * sizeof(nbe_fragment_t)));
+    NBE_HIP(hipMalloc((void**)&d->d_nfrag, 2 * sizeof(int)));
+    NBE_HIP(hipHostMalloc((void**)&d->h_frags, NBE_DIST_MAX_FRAGMENTS * sizeof(nbe_fragment_t), hipHostMallocDefault));
+    NBE_HIP(hipHostMalloc((void**)&d->h_small, (16 + (W2 + 1) * 2 + W2 * NBE_DIST_MAX_FRAGMENTS) * sizeof(int), hipHostMallocDefault));
+    NBE_HIP(hipMalloc((void**)&d->d_aabb, (1024 + 1) * 6 * sizeof(double)));
+    NBE_HIP(hipHostMalloc((void**)&d->h_aabb, 6 * sizeof(double), hipHostMallocDefault));
+    NBE_HIP(hipMalloc((void**)&d->x_diff, nodes2 * 4));
+    NBE_HIP(hipMalloc((void**)&d->x_cover, nodes2 * 4));
+    NBE_HIP(hipMalloc((void**)&d->x_flag, nodes2 * 4));
+    NBE_HIP(hipMalloc((void**)&d->x_index, nodes2 * 4));
+    // With few bodies per rank every other rank needs most of a rank's tree; with many, a small part of it.
+    const size_t others = W2 > 5 ? 4 : (W2 > 1 ? W2 - 1 : 1);
+    d->export_cap = nodes2 * others;
+    d->import_cap = nodes2 * others;
+    d->let_cap = nodes2 + d->import_cap + (size_t)NBE_DIST_MAX_FRAGMENTS * W2;
+    if (d->let_cap * node_bytes >= (1ull << 32) && !e->force64) d->let_cap = ((1ull << 32) - 64) / node_bytes;   // the walk's 32-bit byte offsets
+    NBE_HIP(hipMalloc(&d->export_nodes, d->export_cap * node_bytes));
+    NBE_HIP(hipMalloc(&d->import_nodes, d->import_cap * node_bytes));
+    NBE_HIP(hipMalloc(&d->let_nodes, (d->let_cap + 2) * node_bytes));
+    NBE_HIP(hipMemsetAsync(d->let_nodes, 0, (d->let_cap + 2) * node_bytes, e->stream));
+    NBE_HIP(hipMalloc((void**)&d->let_counters, 16 * sizeof(int)));
+    NBE_HIP(hipMemsetAsync(d->let_counters, 0, 16 * sizeof(int), e->stream));
+    NBE_HIP(hipMalloc((void**)&d->d_export_base, (W2 + 1) * sizeof(unsigned long long)));
+    NBE_HIP(hipMalloc((void**)&d->d_export_sizes, W2 * NBE_DIST_MAX_FRAGMENTS * sizeof(int)));
+    NBE_HIP(hipMalloc((void**)&d->d_boxes, W2 * 6 * sizeof(double)));
+    d->seg_cap = W2 * NBE_DIST_MAX_FRAGMENTS;
+    d->top_cap = W2 * NBE_DIST_MAX_FRAGMENTS;
+    NBE_HIP(hipMalloc((void**)&d->d_segments, d->seg_cap * sizeof(Segment)));
+    NBE_HIP(hipMalloc((void**)&d->d_top, d->top_cap * sizeof(TopCell)));
+    d->split.assign(W2 + 1, 0);
+    d->split[W2] = 1ull << 63;
+    for (size_t r = 1; r < W2; r++) d->split[r] = rank == 0 ? (1ull << 63) : 0;   // until splitters are set: rank 0 would own everything
+    NBE_HIP(hipStreamSynchronize(e->stream));
+    e->stats.n = capacity;
+    e->stats.n_alive = n;
+    return NBE_OK;
+}
+
+extern "C" int nbe_dist_buffers(nbe_engine* e, nbe_dist_buffers_t* out)
+{
+    NBE_TRY(check_dist(e, "nbe_dist_buffers"));
+    if (!out) { nbe_set_error("out is NULL"); return NBE_E_INVALID; }
+    DistState* d = e->dist;
+    out->outbox = d->outbox; out->inbox = d->inbox;
+    out->export_nodes = d->export_nodes; out->import_nodes = d->import_nodes;
+    out->slots = d->cap; out->export_cap = d->export_cap; out->import_cap = d->import_cap;
+    out->record_bytes = (uint32_t)(2 * e->elem);
+    out->node_bytes = (uint32_t)(e->force64 ? sizeof(NodeD) : sizeof(NodeF));
+    return NBE_OK;
+}
+
+// Positions the keys are made from: the force kernels' copy (fp32 for NBE_PREC_MIXED), as the sort uses.
+static const void* key_positions(const nbe_engine* e)
+{
+    return e->cfg.precision == NBE_PREC_MIXED ? (const void*)e->mirror[e->cur] : (const void*)e->posm[e->cur];
+}
+
+__global__ __launch_bounds__(256) void sample_keys_kernel(const uint64_t* __restrict__ keys, const int* __restrict__ counters, int want,
+                                                          uint64_t* __restrict__ out, int* __restrict__ got)
+{
+    const int na = counters[COUNTER_SORTED_ALIVE];
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    const int cnt = na < want ? na : want;
+    if (k == 0) { got[0] = cnt; got[1] = na; }
+    if (k >= cnt) return;
+    // evenly spaced, centred in their strides
+    const long long idx = ((2ll * k + 1) * na) / (2ll * cnt);
+    out[k] = keys[idx];
+}
+
+extern "C" int nbe_dist_sample_keys(nbe_engine* e, size_t max_samples, uint64_t* keys_out, size_t* count, size_t* n_live)
+{
+    NBE_TRY(check_dist(e, "nbe_dist_sample_keys"));
+    DistState* d = e->dist;
+    if (!keys_out || !count) { nbe_set_error("NULL argument"); return NBE_E_INVALID; }
+    if (max_samples > d->cap) max_samples = d->cap;
+    e->keys_sorted = false;
+    NBE_TRY(tree_sort_keys(e));                       // keys of the current state, sorted, in tw.keys[0]
+    e->keys_sorted = false;                           // (the state changes before the build: it sorts again)
+    uint64_t* tmp = (uint64_t*)d->x_diff;             // 2 cap + 2 words of 4 bytes: room for cap keys
+    hipLaunchKernelGGL(sample_keys_kernel, dim3(cdiv(max_samples ? max_samples : 1, 256)), dim3(256), 0, e->stream, e->tw.keys[0],
+                       e->tw.counters, (int)max_samples, tmp, d->d_nfrag);
+    NBE_HIP(hipGetLastError());
+    NBE_HIP(hipMemcpyAsync(d->h_small, d->d_nfrag, 2 * sizeof(int), hipMemcpyDeviceToHost, e->stream));
+    NBE_HIP(hipStreamSynchronize(e->stream));
+    const size_t got = (size_t)d->h_small[0];
+    if (got) NBE_HIP(hipMemcpy(keys_out, tmp, got * 8, hipMemcpyDeviceToHost));
+    *count = got;
+    if (n_live) *n_live = (size_t)d->h_small[1];
+    return NBE_OK;
+}
+
+extern "C" int nbe_dist_set_splitters(nbe_engine* e, const uint64_t* split)
+{
+    NBE_TRY(check_dist(e, "nbe_dist_set_splitters"));
+    DistState* d = e->dist;
+    if (!split) { nbe_set_error("split is NULL"); return NBE_E_INVALID; }
+    if (split[0] != 0 || split[d->world] != (1ull << 63)) { nbe_set_error("split[0] must be 0 and split[world] 2^63"); return NBE_E_INVALID; }
+    for (int r = 0; r < d->world; r++)
+        if (split[r] > split[r + 1]) { nbe_set_error("splitters must not decrease"); return NBE_E_INVALID; }
+    d->split.assign(split, split + d->world + 1);
+    NBE_HIP(hipMemcpyAsync(d->d_split, d->split.data(), (d->world + 1) * 8, hipMemcpyHostToDevice, e->stream));
+    NBE_HIP(hipStreamSynchronize(e->stream));
+    return NBE_OK;
+}
+
+// ---- migration ---------------------------------------------------------------------------------------------------
+// Owner of a key: the number of splitters split[1 .. world-1] that are <= key.
+__device__ __forceinline__ int owner_of(const uint64_t* __restrict__ split, int world, uint64_t key)
+{
+    int lo = 0, hi = world - 1;                       // answer in [lo, hi]
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (split[mid] <= key) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+template <typename R4>
+__global__ __launch_bounds__(256) void classify_kernel(const R4* __restrict__ posk, int slots, double lox, double loy, double loz, double W,
+                                                       const uint64_t* __restrict__ split, int world, int rank, uint32_t* __restrict__ counts)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= slots) return;
+    const R4 p = posk[i];
+    const uint64_t key = body_key((double)p.x, (double)p.y, (double)p.z, lox, loy, loz, W);
+    if (key == KEY_DEAD) return;
+    const int dest = owner_of(split, world, key);
+    if (dest != rank) atomicAdd(&counts[dest], 1u);
+}
+
+// A record is the body's position+mass element followed by its velocity element, whose unused fourth component carries
+// the run-wide index (as bits in fp32 state, as a value in fp64 state).
+__device__ __forceinline__ void put_index(float4& v, uint32_t idx) { v.w = __uint_as_float(idx); }
+__device__ __forceinline__ void put_index(double4& v, uint32_t idx) { v.w = (double)idx; }
+__device__ __forceinline__ uint32_t get_index(const float4& v) { return __float_as_uint(v.w); }
+__device__ __forceinline__ uint32_t get_index(const double4& v) { return (uint32_t)v.w; }
+
+template <typename R4, typename S4>
+__global__ __launch_bounds__(256) void pack_kernel(const R4* __restrict__ posk, S4* __restrict__ posm, S4* __restrict__ vel,
+                                                   float4* __restrict__ mirror, const uint32_t* __restrict__ orig, int slots, double lox,
+                                                   double loy, double loz, double W, const uint64_t* __restrict__ split, int world,
+                                                   int rank, uint32_t* __restrict__ counts, S4* __restrict__ outbox,
+                                                   uint32_t* __restrict__ free_slots)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= slots) return;
+    const R4 pk = posk[i];
+    const uint64_t key = body_key((double)pk.x, (double)pk.y, (double)pk.z, lox, loy, loz, W);
+    if (key == KEY_DEAD) return;
+    const int dest = owner_of(split, world, key);
+    if (dest == rank) return;
+    const uint32_t at = atomicAdd(&counts[world + dest], 1u);
+    S4 p = posm[i], v = vel[i];
+    put_index(v, orig[i]);
+    outbox[2 * (size_t)at] = p;
+    outbox[2 * (size_t)at + 1] = v;
+    free_slots[atomicAdd(&counts[2 * world], 1u)] = (uint32_t)i;
+    // the slot now holds a massless body parked outside the bound
+    p.x = lox + 2.0 * W; p.y = loy + 2.0 * W; p.z = loz + 2.0 * W; p.w = 0;
+    v.x = 0; v.y = 0; v.z = 0; v.w = 0;
+    posm[i] = p;
+    vel[i] = v;
+    if (mirror) mirror[i] = make_float4((float)p.x, (float)p.y, (float)p.z, 0.0f);
+}
+
+template <typename R4, typename S4>
+static int classify_t(nbe_engine* e, uint32_t* send_counts)
+{
+    DistState* d = e->dist;
+    const int W = d->world;
+    double lo[3], width;
+    bound_lo(e, lo, &width);
+    const int slots = (int)d->live_hi;
+    const R4* posk = (const R4*)key_positions(e);
+    NBE_HIP(hipMemsetAsync(d->d_counts, 0, (2 * (size_t)W + 1) * 4, e->stream));
+    if (slots > 0) {
+        hipLaunchKernelGGL((classify_kernel<R4>), dim3(cdiv(slots, 256)), dim3(256), 0, e->stream, posk, slots, lo[0], lo[1], lo[2], width,
+                           d->d_split, W, d->rank, d->d_counts);
+        NBE_HIP(hipGetLastError());
+    }
+    NBE_HIP(hipMemcpyAsync(d->h_counts, d->d_counts, (size_t)W * 4, hipMemcpyDeviceToHost, e->stream));
+    NBE_HIP(hipStreamSynchronize(e->stream));
+    uint32_t off = 0;
+    for (int r = 0; r < W; r++) { send_counts[r] = d->h_counts[r]; d->h_counts[W + r] = off; off += d->h_counts[r]; }
+    d->n_free = off;
+    if (off > 0) {
+        NBE_HIP(hipMemcpyAsync(d->d_counts + W, d->h_counts + W, (size_t)W * 4, hipMemcpyHostToDevice, e->stream));
+        NBE_TRY(frame_stream_guard_write(e, e->cur));
+        hipLaunchKernelGGL((pack_kernel<R4, S4>), dim3(cdiv(slots, 256)), dim3(256), 0, e->stream, posk, (S4*)e->posm[e->cur],
+                           (S4*)e->vel[e->cur], e->cfg.precision == NBE_PREC_MIXED ? e->mirror[e->cur] : (float4*)nullptr,
+                           e->orig[e->orig_cur], slots, lo[0], lo[1], lo[2], width, d->d_split, W, d->rank, d->d_counts, (S4*)d->outbox,
+                           d->free_slots);
+        NBE_HIP(hipGetLastError());
+        NBE_HIP(hipStreamSynchronize(e->stream));     // the caller reads the outbox on streams of its own
+    }
+    return NBE_OK;
+}
+
+extern "C" int nbe_dist_classify(nbe_engine* e, uint32_t* send_counts)
+{
+    NBE_TRY(check_dist(e, "nbe_dist_classify"));
+    if (!send_counts) { nbe_set_error("send_counts is NULL"); return NBE_E_INVALID; }
+    DistState* d = e->dist;
+    int rc = NBE_E_INVALID;
+    switch (e->cfg.precision) {
+    case NBE_PREC_F32: rc = classify_t<float4, float4>(e, send_counts); break;
+    case NBE_PREC_MIXED: rc = classify_t<float4, double4>(e, send_counts); break;
+    case NBE_PREC_F64: rc = classify_t<double4, double4>(e, send_counts); break;
+    }
+    if (rc == NBE_OK) { d->classified = true; d->built = false; d->exported = false; d->assembled = false; e->prepared = false; e->keys_sorted = false; }
+    return rc;
+}
+
+template <typename S4>
+__global__ __launch_bounds__(256) void append_kernel(const S4* __restrict__ inbox, int k, const uint32_t* __restrict__ free_slots,
+                                                     int n_free, int tail, S4* __restrict__ posm, S4* __restrict__ vel,
+                                                     float4* __restrict__ mirror, uint32_t* __restrict__ orig)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= k) return;
+    const int slot = j < n_free ? (int)free_slots[j] : tail + (j - n_free);
+    const S4 p = inbox[2 * (size_t)j];
+    S4 v = inbox[2 * (size_t)j + 1];
+    orig[slot] = get_index(v);
+    v.w = 0;
+    posm[slot] = p;
+    vel[slot] = v;
+    if (mirror) mirror[slot] = make_float4((float)p.x, (float)p.y, (float)p.z, (float)p.w);
+}
+
+extern "C" int nbe_dist_receive(nbe_engine* e, size_t k)
+{
+    NBE_TRY(check_dist(e, "nbe_dist_receive"));
+    DistState* d = e->dist;
+    if (!d->classified) { nbe_set_error("nbe_dist_receive before nbe_dist_classify"); return NBE_E_INVALID; }
+    const size_t extra = k > d->n_free ? k - d->n_free : 0;
+    if (d->live_hi + extra > d->cap) {
+        nbe_set_error("rank %d: %zu bodies arrive but only %zu slots are free (capacity %zu)", d->rank, k, d->cap - d->live_hi + d->n_free, d->cap);
+        return NBE_E_NOMEM;
+    }
+    if (k > 0) {
+        float4* mirror = e->cfg.precision == NBE_PREC_MIXED ? e->mirror[e->cur] : nullptr;
+        if (e->state64)
+            hipLaunchKernelGGL((append_kernel<double4>), dim3(cdiv(k, 256)), dim3(256), 0, e->stream, (const double4*)d->inbox, (int)k,
+                               d->free_slots, (int)d->n_free, (int)d->live_hi, (double4*)e->posm[e->cur], (double4*)e->vel[e->cur], mirror,
+                               e->orig[e->orig_cur]);
+        else
+            hipLaunchKernelGGL((append_kernel<float4>), dim3(cdiv(k, 256)), dim3(256), 0, e->stream, (const float4*)d->inbox, (int)k,
+                               d->free_slots, (int)d->n_free, (int)d->live_hi, (float4*)e->posm[e->cur], (float4*)e->vel[e->cur], mirror,
+                               e->orig[e->orig_cur]);
+        NBE_HIP(hipGetLastError());
+    }
+    d->live_hi += extra;
+    d->n_free = d->n_free > k ? d->n_free - (uint32_t)k : 0;     // (slots still vacant are parked bodies: the sort drops them)
+    return NBE_OK;
+}
+
+// ---- build: local tree, fragments, bounding box ---------------------------------------------------------------------
+// Is the depth-`level` cell around `key` wholly inside [lo, hi)?  (A body, level 255, always is: it is here because its
+// key is.)
+__device__ __forceinline__ bool cell_inside(uint64_t key, int level, uint64_t lo, uint64_t hi)
+{
+    if (level >= 21) return true;
+    const uint64_t size = 1ull << (3 * (21 - level));
+    const uint64_t cmin = key & ~(size - 1ull);
+    return cmin >= lo && cmin + (size - 1ull) < hi;
+}
+
+// A node roots a fragment iff its cell is inside the rank's key range and the cell of the node above is not.
+__global__ __launch_bounds__(256) void fragments_kernel(const CNode* __restrict__ cn, const int* __restrict__ counters,
+                                                        const double* __restrict__ node_sum, uint64_t lo, uint64_t hi,
+                                                        nbe_fragment_t* __restrict__ frags, int* __restrict__ nfrag)
+{
+    const int total = counters[1];
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= total) return;
+    const CNode c = cn[p];
+    const bool leaf = c.body >= 0;
+    if (!leaf && !cell_inside(c.key, c.level, lo, hi)) return;
+    if (c.plevel != 255 && cell_inside(c.key, c.plevel, lo, hi)) return;
+    const int at = atomicAdd(nfrag, 1);
+    if (at >= NBE_DIST_MAX_FRAGMENTS) return;
+    nbe_fragment_t f;
+    f.key = c.key;
+    f.level = leaf ? 255 : (int)c.level;
+    f.start = p;
+    f.nodes = c.skip - p;
+    f.reserved = 0;
+    for (int k = 0; k < 4; k++) f.sum[k] = node_sum[4 * (size_t)p + k];
+    frags[at] = f;
+}
+
+template <typename R4>
+__global__ __launch_bounds__(256) void aabb_partial_kernel(const R4* __restrict__ pos, const int* __restrict__ counters, double* __restrict__ part)
+{
+    const int na = counters[0];
+    double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < na; i += gridDim.x * 256) {
+        const R4 p = pos[i];
+        const double v[3] = {(double)p.x, (double)p.y, (double)p.z};
+        for (int c = 0; c < 3; c++) { mn[c] = fmin(mn[c], v[c]); mx[c] = fmax(mx[c], v[c]); }
+    }
+    __shared__ double s[6][256];
+    for (int c = 0; c < 3; c++) { s[c][threadIdx.x] = mn[c]; s[3 + c][threadIdx.x] = mx[c]; }
+    __syncthreads();
+    for (int w = 128; w >= 1; w >>= 1) {
+        if ((int)threadIdx.x < w)
+            for (int c = 0; c < 3; c++) {
+                s[c][threadIdx.x] = fmin(s[c][threadIdx.x], s[c][threadIdx.x + w]);
+                s[3 + c][threadIdx.x] = fmax(s[3 + c][threadIdx.x], s[3 + c][threadIdx.x + w]);
+            }
+        __syncthreads();
+    }
+    if (threadIdx.x < 6) part[blockIdx.x * 6 + threadIdx.x] = s[threadIdx.x][0];
+}
+
+__global__ __launch_bounds__(64) void aabb_final_kernel(const double* __restrict__ part, int nparts, double* __restrict__ out)
+{
+    const int c = threadIdx.x;
+    if (c >= 6) return;
+    double v = c < 3 ? INFINITY : -INFINITY;
+    for (int b = 0; b < nparts; b++) v = c < 3 ? fmin(v, part[b * 6 + c]) : fmax(v, part[b * 6 + c]);
+    out[c] = v;
+}
+
+extern "C" int nbe_dist_build(nbe_engine* e, nbe_fragment_t* frags, int max, int* count, double aabb[6], uint64_t* n_live)
+{
+    NBE_TRY(check_dist(e, "nbe_dist_build"));
+    DistState* d = e->dist;
+    if (!frags || !count || !aabb) { nbe_set_error("NULL argument"); return NBE_E_INVALID; }
+    e->keys_sorted = false;
+    NBE_TRY(tree_sort_and_build(e));
+    NBE_TRY(collide_emit_geometry(e));
+    NBE_HIP(hipMemsetAsync(d->d_nfrag, 0, 2 * sizeof(int), e->stream));
+    const size_t n = e->n;
+    hipLaunchKernelGGL(fragments_kernel, dim3(cdiv(2 * n, 256)), dim3(256), 0, e->stream, e->cw.cnodes, e->tw.counters, e->tw.node_sum,
+                       d->split[d->rank], d->split[d->rank + 1], d->d_frags, d->d_nfrag);
+    const int parts = (int)std::min<size_t>(1024, cdiv(n, 256));
+    if (e->cfg.precision == NBE_PREC_F64)
+        hipLaunchKernelGGL((aabb_partial_kernel<double4>), dim3(parts), dim3(256), 0, e->stream, (const double4*)key_positions(e),
+                           e->tw.counters, d->d_aabb + 6);
+    else
+        hipLaunchKernelGGL((aabb_partial_kernel<float4>), dim3(parts), dim3(256), 0, e->stream, (const float4*)key_positions(e),
+                           e->tw.counters, d->d_aabb + 6);
+    hipLaunchKernelGGL(aabb_final_kernel, dim3(1), dim3(64), 0, e->stream, d->d_aabb + 6, parts, d->d_aabb);
+    NBE_HIP(hipGetLastError());
+    NBE_HIP(hipMemcpyAsync(d->h_small, e->tw.counters, 4 * sizeof(int), hipMemcpyDeviceToHost, e->stream));
+    NBE_HIP(hipMemcpyAsync(d->h_small + 4, d->d_nfrag, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+    NBE_HIP(hipMemcpyAsync(d->h_frags, d->d_frags, NBE_DIST_MAX_FRAGMENTS * sizeof(nbe_fragment_t), hipMemcpyDeviceToHost, e->stream));
+    NBE_HIP(hipMemcpyAsync(d->h_aabb, d->d_aabb, 6 * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    NBE_HIP(hipStreamSynchronize(e->stream));
+    const int na = d->h_small[0], nf = d->h_small[4];
+    if (nf > NBE_DIST_MAX_FRAGMENTS || nf > max) { nbe_set_error("rank %d has %d fragments (limit %d)", d->rank, nf, std::min(max, NBE_DIST_MAX_FRAGMENTS)); return NBE_E_UNSUPPORTED; }
+    d->my_frags.assign(d->h_frags, d->h_frags + nf);
+    std::sort(d->my_frags.begin(), d->my_frags.end(), [](const nbe_fragment_t& a, const nbe_fragment_t& b) { return a.key < b.key; });
+    if (nf) memcpy(frags, d->my_frags.data(), (size_t)nf * sizeof(nbe_fragment_t));
+    *count = nf;
+    memcpy(aabb, d->h_aabb, 6 * sizeof(double));
+    if (n_live) *n_live = (uint64_t)na;
+    d->live_hi = (size_t)na;          // the sort has packed the live bodies into the first slots
+    d->n_free = 0;
+    d->built = true; d->classified = false; d->exported = false; d->assembled = false;
+    e->prepared = true;
+    e->stats.n_alive = (uint64_t)na;
+    e->stats.tree_nodes = (uint64_t)d->h_small[1];
+    e->stats.tree_cells = (uint64_t)d->h_small[2];
+    e->host_nalive = (size_t)na;
+    return NBE_OK;
+}
+
+// ---- export: fragments pruned for another rank -------------------------------------------------------------------------
+// Can any point of the box [mn, mx] pass the opening test of this cell?  The test a body applies (tree_walk.hip) is
+// r^2 < edge^2/theta^2 on fp32 records (both sides carry eps^2 with softening) and edge / r > theta on fp64 ones, with r
+// measured from the cell's centre of mass.  The distance from that centre to the box bounds r from below; `slack` (absolute,
+// in metres) and `rel` cover the rounding of the body's own arithmetic, so a cell judged closed here is closed for every
+// body in the box whatever its roundings.
+__device__ __forceinline__ double box_distance(double x, double y, double z, const double* __restrict__ b)
+{
+    const double dx = fmax(fmax(b[0] - x, x - b[3]), 0.0), dy = fmax(fmax(b[1] - y, y - b[4]), 0.0), dz = fmax(fmax(b[2] - z, z - b[5]), 0.0);
+    return sqrt(dx * dx + dy * dy + dz * dz);
+}
+__device__ __forceinline__ bool may_open(const NodeF& nd, const double* __restrict__ box, double theta, double eps2, double slack, double rel)
+{
+    if (!(nd.w2 > 0.0f)) return false;                // a body: never opened
+    const double dlow = fmax(box_distance((double)nd.x, (double)nd.y, (double)nd.z, box) - slack, 0.0);
+    return dlow * dlow * (1.0 - rel) < (double)nd.w2 * (1.0 + rel);      // (eps^2 left out on the left: errs towards "may open")
+}
+__device__ __forceinline__ bool may_open(const NodeD& nd, const double* __restrict__ box, double theta, double, double slack, double rel)
+{
+    if (!(nd.w > 0.0)) return false;
+    const double dlow = fmax(box_distance(nd.x, nd.y, nd.z, box) - slack, 0.0);
+    return nd.w * nd.w * (1.0 + rel) >= theta * theta * dlow * dlow * (1.0 - rel);
+}
+
+// Cells inside the rank's key range that the box cannot open hide everything below them: +1 on the node after, -1 on
+// the node after their subtree; the running sum is then the number of such cells above a node.
+template <typename NodeT>
+__global__ __launch_bounds__(256) void export_mark_kernel(const NodeT* __restrict__ nodes, const CNode* __restrict__ cn,
+                                                          const int* __restrict__ counters, uint64_t lo, uint64_t hi,
+                                                          const double* __restrict__ box, double theta, double eps2, double slack,
+                                                          double rel, uint32_t* __restrict__ diff)
+{
+    const int total = counters[1];
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= total) return;
+    const CNode c = cn[p];
+    if (c.body >= 0 || !cell_inside(c.key, c.level, lo, hi)) return;
+    if (may_open(nodes[p], box, theta, eps2, slack, rel)) return;
+    atomicAdd(&diff[p + 1], 1u);
+    atomicAdd(&diff[c.skip], 0xffffffffu);
+}
+
+// cover = exclusive scan of diff: cover[p + 1] is the running sum up to and including p.
+__global__ __launch_bounds__(256) void export_flag_kernel(const CNode* __restrict__ cn, const int* __restrict__ counters, uint64_t lo,
+                                                          uint64_t hi, const uint32_t* __restrict__ cover, uint32_t* __restrict__ flag)
+{
+    const int total = counters[1];
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p > total) return;
+    if (p == total) { flag[p] = 0; return; }
+    const CNode c = cn[p];
+    const bool in = c.body >= 0 || cell_inside(c.key, c.level, lo, hi);
+    flag[p] = (in && cover[p + 1] == 0u) ? 1u : 0u;
+}
+
+// base[dest + 1] = base[dest] + exported nodes; sizes of the fragments in this export; flags an overflow of the buffer.
+__global__ __launch_bounds__(256) void export_sizes_kernel(const int* __restrict__ counters, const uint32_t* __restrict__ index,
+                                                           const nbe_fragment_t* __restrict__ frags, int nfrag, int dest,
+                                                           unsigned long long* __restrict__ base, unsigned long long cap,
+                                                           int* __restrict__ sizes, int* __restrict__ overflow)
+{
+    const int total = counters[1];
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    if (f == 0) {
+        const unsigned long long nb = base[dest] + index[total];
+        base[dest + 1] = nb;
+        if (nb > cap) *overflow = 1;
+    }
+    if (f < nfrag) sizes[f] = (int)(index[frags[f].start + frags[f].nodes] - index[frags[f].start]);
+}
+
+template <typename NodeT>
+__global__ __launch_bounds__(256) void export_write_kernel(const NodeT* __restrict__ nodes, const int* __restrict__ counters,
+                                                           const uint32_t* __restrict__ flag, const uint32_t* __restrict__ index,
+                                                           const unsigned long long* __restrict__ base, int dest, unsigned long long cap,
+                                                           NodeT* __restrict__ out)
+{
+    const int total = counters[1];
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= total || !flag[p]) return;
+    if (base[dest + 1] > cap) return;                 // overflow: reported by the host, nothing written
+    NodeT nd = nodes[p];
+    nd.skip = (int)index[nd.skip];                    // relative to the first node of this export
+    out[base[dest] + index[p]] = nd;
+}
+
+template <typename NodeT>
+static int export_t(nbe_engine* e, int32_t* export_sizes, uint64_t* export_offsets)
+{
+    DistState* d = e->dist;
+    const int W = d->world;
+    const int nf = (int)d->my_frags.size();
+    const size_t n = e->n;
+    const unsigned grid = cdiv(2 * n + 1, 256);
+    const uint64_t lo = d->split[d->rank], hi = d->split[d->rank + 1];
+    const double eps2 = e->cfg.eps * e->cfg.eps;
+    // rounding of a body's own distance: its coordinates and the node's are within the bound (|x| <= |centre| + width),
+    // each difference is off by at most an ulp of that, in the precision of the walk
+    double reach = e->cfg.bound_width;
+    for (int c = 0; c < 3; c++) reach = fmax(reach, fabs(e->cfg.bound_center[c]) + e->cfg.bound_width);
+    const double ulp = e->force64 ? 2.3e-16 : 1.2e-7;
+    const double slack = 4.0 * ulp * reach, rel = 16.0 * ulp;
+    NBE_HIP(hipMemsetAsync(d->d_export_base, 0, sizeof(unsigned long long), e->stream));
+    NBE_HIP(hipMemsetAsync(d->d_nfrag + 1, 0, sizeof(int), e->stream));
+    NBE_HIP(hipMemcpyAsync(d->d_frags, d->my_frags.data(), (size_t)nf * sizeof(nbe_fragment_t), hipMemcpyHostToDevice, e->stream));
+    for (int q = 0; q < W; q++) {
+        if (q == d->rank || nf == 0) {               // nothing goes to oneself
+            hipLaunchKernelGGL(export_sizes_kernel, dim3(1), dim3(256), 0, e->stream, d->let_counters + 8, d->x_index, d->d_frags, 0, q,
+                               d->d_export_base, (unsigned long long)d->export_cap, d->d_export_sizes + (size_t)q * NBE_DIST_MAX_FRAGMENTS,
+                               d->d_nfrag + 1);      // (counters[1] = 0 and index[0] = 0 there: adds nothing)
+            continue;
+        }
+        NBE_HIP(hipMemsetAsync(d->x_diff, 0, (2 * n + 2) * 4, e->stream));
+        hipLaunchKernelGGL((export_mark_kernel<NodeT>), dim3(grid), dim3(256), 0, e->stream, (const NodeT*)e->tw.nodes, e->cw.cnodes,
+                           e->tw.counters, lo, hi, d->d_boxes + 6 * (size_t)q, e->cfg.theta, eps2, slack, rel, d->x_diff);
+        NBE_TRY(device_scan_u32(e, d->x_diff, d->x_cover, 2 * n + 2));
+        hipLaunchKernelGGL(export_flag_kernel, dim3(grid), dim3(256), 0, e->stream, e->cw.cnodes, e->tw.counters, lo, hi, d->x_cover, d->x_flag);
+        NBE_TRY(device_scan_u32(e, d->x_flag, d->x_index, 2 * n + 2));
+        hipLaunchKernelGGL(export_sizes_kernel, dim3(cdiv(nf, 256)), dim3(256), 0, e->stream, e->tw.counters, d->x_index, d->d_frags, nf, q,
+                           d->d_export_base, (unsigned long long)d->export_cap, d->d_export_sizes + (size_t)q * NBE_DIST_MAX_FRAGMENTS,
+                           d->d_nfrag + 1);
+        hipLaunchKernelGGL((export_write_kernel<NodeT>), dim3(grid), dim3(256), 0, e->stream, (const NodeT*)e->tw.nodes, e->tw.counters,
+                           d->x_flag, d->x_index, d->d_export_base, q, (unsigned long long)d->export_cap, (NodeT*)d->export_nodes);
+        NBE_HIP(hipGetLastError());
+    }
+    // read back: offsets, overflow flag, sizes
+    unsigned long long* h_base = (unsigned long long*)(d->h_small + 16);
+    int* h_sizes = d->h_small + 16 + 2 * (W + 1);
+    NBE_HIP(hipMemcpyAsync(h_base, d->d_export_base, (size_t)(W + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost, e->stream));
+    NBE_HIP(hipMemcpyAsync(d->h_small, d->d_nfrag, 2 * sizeof(int), hipMemcpyDeviceToHost, e->stream));
+    if (nf)
+        for (int q = 0; q < W; q++)
+            NBE_HIP(hipMemcpyAsync(h_sizes + (size_t)q * nf, d->d_export_sizes + (size_t)q * NBE_DIST_MAX_FRAGMENTS, (size_t)nf * sizeof(int),
+                                   hipMemcpyDeviceToHost, e->stream));
+    NBE_HIP(hipStreamSynchronize(e->stream));
+    if (d->h_small[1]) { nbe_set_error("rank %d: the export buffer (%zu nodes) is too small", d->rank, d->export_cap); return NBE_E_NOMEM; }
+    for (int q = 0; q <= W; q++) export_offsets[q] = (uint64_t)h_base[q];
+    for (int q = 0; q < W; q++)
+        for (int f = 0; f < nf; f++) export_sizes[(size_t)q * nf + f] = q == d->rank ? 0 : h_sizes[(size_t)q * nf + f];
+    return NBE_OK;
+}
+
+extern "C" int nbe_dist_export(nbe_engine* e, const nbe_fragment_t* all_frags, const int* frag_counts, const double* aabbs,
+                               int32_t* export_sizes, uint64_t* export_offsets)
+{
+    NBE_TRY(check_dist(e, "nbe_dist_export"));
+    DistState* d = e->dist;
+    if (!frag_counts || !aabbs || !export_sizes || !export_offsets) { nbe_set_error("NULL argument"); return NBE_E_INVALID; }
+    if (!d->built) { nbe_set_error("nbe_dist_export before nbe_dist_build"); return NBE_E_INVALID; }
+    size_t total = 0;
+    for (int r = 0; r < d->world; r++) {
+        if (frag_counts[r] < 0 || frag_counts[r] > NBE_DIST_MAX_FRAGMENTS) { nbe_set_error("bad fragment count of rank %d", r); return NBE_E_INVALID; }
+        total += (size_t)frag_counts[r];
+    }
+    if (frag_counts[d->rank] != (int)d->my_frags.size()) { nbe_set_error("frag_counts[%d] is not what nbe_dist_build returned", d->rank); return NBE_E_INVALID; }
+    if (total > 0 && !all_frags) { nbe_set_error("all_frags is NULL"); return NBE_E_INVALID; }
+    d->all_frags.assign(all_frags, all_frags + total);
+    d->frag_counts.assign(frag_counts, frag_counts + d->world);
+    NBE_HIP(hipMemcpyAsync(d->d_boxes, aabbs, (size_t)d->world * 6 * sizeof(double), hipMemcpyHostToDevice, e->stream));
+    NBE_HIP(hipMemsetAsync(d->let_counters + 8, 0, 2 * sizeof(int), e->stream));
+    NBE_HIP(hipMemsetAsync(d->x_index, 0, 4, e->stream));
+    int rc = e->force64 ? export_t<NodeD>(e, export_sizes, export_offsets) : export_t<NodeF>(e, export_sizes, export_offsets);
+    if (rc == NBE_OK) d->exported = true;
+    return rc;
+}
+
+// ---- the cells above the fragments, and the layout of the assembled array ---------------------------------------------------
+struct FragRef { uint64_t key; int rank, idx, size; const double* sum; };
+
+struct Layout {
+    std::vector<Segment> segs;
+    std::vector<TopCell> tops;
+    int total = 0;
+};
+
+// Depth of the smallest cell that holds both keys (63-bit keys, 3 bits per level).
+static int common_level(uint64_t a, uint64_t b)
+{
+    if (a == b) return 21;
+    const int d = __builtin_clzll(a ^ b) - 1;
+    const int l = d / 3;
+    return l > 21 ? 21 : l;
+}
+
+// Lays out fragments [i, j), which share a cell, in pre-order from index `at`; returns the number of nodes and leaves the
+// fp64 sums of what it laid out in `sum`.  A cell sums its children in octant order starting from zero, as cell_mass_kernel.
+static int layout_range(const std::vector<FragRef>& fr, int i, int j, int at, const std::vector<Segment>& seg_of, Layout* out, double sum[4])
+{
+    if (j - i == 1) {
+        Segment s = seg_of[(size_t)i];
+        s.dst = at;
+        s.rebase += at;
+        out->segs.push_back(s);
+        for (int k = 0; k < 4; k++) sum[k] = fr[(size_t)i].sum[k];
+        return s.count;
+    }
+    const int L = common_level(fr[(size_t)i].key, fr[(size_t)j - 1].key);
+    const size_t me = out->tops.size();
+    out->tops.push_back(TopCell{at, 0, L, {0, 0, 0, 0}});
+    int n = 1;
+    double acc[4] = {0, 0, 0, 0};
+    int a = i;
+    while (a < j) {
+        const unsigned digit = L >= 21 ? 0u : (unsigned)(fr[(size_t)a].key >> (3 * (20 - L))) & 7u;
+        int b = a + 1;
+        while (b < j && L < 21 && ((unsigned)(fr[(size_t)b].key >> (3 * (20 - L))) & 7u) == digit) b++;
+        double cs[4];
+        n += layout_range(fr, a, b, at + n, seg_of, out, cs);
+        for (int k = 0; k < 4; k++) acc[k] += cs[k];
+        a = b;
+    }
+    TopCell& t = out->tops[me];
+    t.skip = at + n;
+    for (int k = 0; k < 4; k++) { t.sum[k] = acc[k]; sum[k] = acc[k]; }
+    return n;
+}
+
+template <typename NodeT>
+__global__ __launch_bounds__(256) void top_cells_kernel(const TopCell* __restrict__ tops, int ntops, double bound_width, double theta,
+                                                        double eps2, int total, NodeT* __restrict__ out)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t == 0) {
+        // the record behind the last node, as the build leaves one: massless, never opens, skips to itself
+        NodeT snt;
+        snt.x = 0; snt.y = 0; snt.z = 0; snt.m = 0;
+        set_edge<NodeT>(snt, 0.0, theta, eps2);
+        snt.skip = total;
+        out[total] = snt;
+    }
+    if (t >= ntops) return;
+    const TopCell c = tops[t];
+    NodeT nd;
+    const double m = c.sum[0];
+    const double inv = m != 0.0 ? 1.0 / m : 0.0;
+    nd.x = c.sum[1] * inv; nd.y = c.sum[2] * inv; nd.z = c.sum[3] * inv; nd.m = m;
+    set_edge<NodeT>(nd, bound_width * (1.0 / (double)(1u << c.level)), theta, eps2);
+    nd.skip = c.skip;
+    out[c.dst] = nd;
+}
+
+// One workgroup per 256 nodes of a segment would need a work list; instead every thread finds its segment by bisection
+// over the segments' first indices (a few thousand at most, cached).
+template <typename NodeT>
+__global__ __launch_bounds__(256) void assemble_kernel(const Segment* __restrict__ segs, int nsegs, const int* __restrict__ seg_first,
+                                                       const NodeT* __restrict__ own, const NodeT* __restrict__ imported,
+                                                       long long work, NodeT* __restrict__ out)
+{
+    const long long w = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (w >= work) return;
+    int lo = 0, hi = nsegs - 1;                       // last segment whose first work item is <= w
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if ((long long)seg_first[mid] <= w) lo = mid; else hi = mid - 1;
+    }
+    const Segment s = segs[lo];
+    const int k = (int)(w - seg_first[lo]);
+    NodeT nd = s.remote ? imported[s.src + k] : own[s.src + k];
+    nd.skip += s.rebase;
+    out[s.dst + k] = nd;
+}
+
+extern "C" int nbe_dist_assemble(nbe_engine* e, const int32_t* import_sizes, const uint64_t* import_offsets)
+{
+    NBE_TRY(check_dist(e, "nbe_dist_assemble"));
+    DistState* d = e->dist;
+    if (!d->exported) { nbe_set_error("nbe_dist_assemble before nbe_dist_export"); return NBE_E_INVALID; }
+    if (!import_sizes || !import_offsets) { nbe_set_error("NULL argument"); return NBE_E_INVALID; }
+    const int W = d->world;
+    std::vector<FragRef> fr;
+    std::vector<Segment> seg_of;
+    size_t g = 0;
+    for (int r = 0; r < W; r++) {
+        int within = 0;                               // nodes of rank r's export to this rank before the fragment
+        for (int f = 0; f < d->frag_counts[(size_t)r]; f++, g++) {
+            const nbe_fragment_t& fg = d->all_frags[g];
+            Segment s;
+            s.dst = 0;
+            if (r == d->rank) {
+                // own fragment: the subtree as the build left it; its skips are indices of the own node array
+                s.count = fg.nodes; s.src = fg.start; s.rebase = -fg.start; s.remote = 0;
+            } else {
+                // imported: skips are relative to the first node of r's export to this rank
+                s.count = import_sizes[g]; s.src = (int)import_offsets[r] + within; s.rebase = -within; s.remote = 1;
+                if (s.count < 1 || (size_t)s.src + (size_t)s.count > d->import_cap) { nbe_set_error("bad import size of fragment %d of rank %d", f, r); return NBE_E_INVALID; }
+                within += s.count;
+            }
+            if (!fr.empty() && !(fr.back().key < fg.key)) { nbe_set_error("fragments are not in key order (rank %d, fragment %d)", r, f); return NBE_E_INVALID; }
+            fr.push_back(FragRef{fg.key, r, f, s.count, fg.sum});
+            seg_of.push_back(s);
+        }
+    }
+    Layout lay;
+    double sum[4];
+    if (!fr.empty()) lay.total = layout_range(fr, 0, (int)fr.size(), 0, seg_of, &lay, sum);
+    if ((size_t)lay.total > d->let_cap) { nbe_set_error("rank %d: the assembled tree (%d nodes) exceeds the buffer (%zu)", d->rank, lay.total, d->let_cap); return NBE_E_NOMEM; }
+    if (lay.segs.size() > d->seg_cap || lay.tops.size() > d->top_cap) { nbe_set_error("too many fragments"); return NBE_E_UNSUPPORTED; }
+    // work items: the nodes of all segments, numbered segment after segment
+    std::vector<int> seg_first(lay.segs.size());
+    long long work = 0;
+    for (size_t s = 0; s < lay.segs.size(); s++) { seg_first[s] = (int)work; work += lay.segs[s].count; }
+    int* d_seg_first = (int*)d->x_diff;               // free between export and the next one
+    if (!lay.segs.empty()) {
+        NBE_HIP(hipMemcpyAsync(d->d_segments, lay.segs.data(), lay.segs.size() * sizeof(Segment), hipMemcpyHostToDevice, e->stream));
+        NBE_HIP(hipMemcpyAsync(d_seg_first, seg_first.data(), seg_first.size() * sizeof(int), hipMemcpyHostToDevice, e->stream));
+    }
+    if (!lay.tops.empty())
+        NBE_HIP(hipMemcpyAsync(d->d_top, lay.tops.data(), lay.tops.size() * sizeof(TopCell), hipMemcpyHostToDevice, e->stream));
+    const double eps2 = e->cfg.eps * e->cfg.eps;
+    const int ntops = (int)lay.tops.size();
+    if (e->force64) {
+        hipLaunchKernelGGL((top_cells_kernel<NodeD>), dim3(cdiv(ntops + 1, 256)), dim3(256), 0, e->stream, d->d_top, ntops, e->cfg.bound_width,
+                           e->cfg.theta, eps2, lay.total, (NodeD*)d->let_nodes);
+        if (work > 0)
+            hipLaunchKernelGGL((assemble_kernel<NodeD>), dim3(cdiv((size_t)work, 256)), dim3(256), 0, e->stream, d->d_segments,
+                               (int)lay.segs.size(), d_seg_first, (const NodeD*)e->tw.nodes, (const NodeD*)d->import_nodes, work,
+                               (NodeD*)d->let_nodes);
+    } else {
+        hipLaunchKernelGGL((top_cells_kernel<NodeF>), dim3(cdiv(ntops + 1, 256)), dim3(256), 0, e->stream, d->d_top, ntops, e->cfg.bound_width,
+                           e->cfg.theta, eps2, lay.total, (NodeF*)d->let_nodes);
+        if (work > 0)
+            hipLaunchKernelGGL((assemble_kernel<NodeF>), dim3(cdiv((size_t)work, 256)), dim3(256), 0, e->stream, d->d_segments,
+                               (int)lay.segs.size(), d_seg_first, (const NodeF*)e->tw.nodes, (const NodeF*)d->import_nodes, work,
+                               (NodeF*)d->let_nodes);
+    }
+    NBE_HIP(hipGetLastError());
+    const int cnt[2] = {(int)d->live_hi, lay.total};
+    NBE_HIP(hipMemcpyAsync(d->let_counters, cnt, sizeof(cnt), hipMemcpyHostToDevice, e->stream));
+    NBE_HIP(hipStreamSynchronize(e->stream));         // the host vectors above go out of scope
+    d->assembled = true;
+    e->stats.tree_nodes = (uint64_t)lay.total;
+    return NBE_OK;
+}
+
+// ---- force pass + update ---------------------------------------------------------------------------------------------------
+extern "C" int nbe_dist_advance(nbe_engine* e)
+{
+    NBE_TRY(check_dist(e, "nbe_dist_advance"));
+    DistState* d = e->dist;
+    if (!d->assembled) { nbe_set_error("nbe_dist_advance before nbe_dist_assemble"); return NBE_E_INVALID; }
+    NBE_TRY(frame_stream_guard_write(e, e->cur ^ 1));
+    // the walk reads the node array and the two counters through the engine's tree workspace
+    void* nodes = e->tw.nodes;
+    int* counters = e->tw.counters;
+    e->tw.nodes = d->let_nodes;
+    e->tw.counters = d->let_counters;
+    const int rc = tree_forces(e, e->cur, 0, e->n, true, false, e->cur ^ 1);
+    e->tw.nodes = nodes;
+    e->tw.counters = counters;
+    NBE_TRY(rc);
+    e->cur ^= 1;
+    e->prepared = false;
+    d->assembled = false; d->built = false; d->exported = false;
+    e->stats.steps++;
+    return NBE_OK;
+}
+
+extern "C" int nbe_dist_download(nbe_engine* e, uint64_t* index, double* pos, double* vel, double* mass, size_t* count)
+{
+    NBE_TRY(check_dist(e, "nbe_dist_download"));
+    DistState* d = e->dist;
+    if (!count) { nbe_set_error("count is NULL"); return NBE_E_INVALID; }
+    const size_t k = d->live_hi;
+    *count = 0;
+    if (k == 0) return NBE_OK;
+    std::vector<uint32_t> ho(k);
+    std::vector<double> hp, hv;
+    std::vector<float> fp, fv;
+    NBE_HIP(hipMemcpyAsync(ho.data(), e->orig[e->orig_cur], k * 4, hipMemcpyDeviceToHost, e->stream));
+    if (e->state64) {
+        hp.resize(4 * k); hv.resize(4 * k);
+        NBE_HIP(hipMemcpyAsync(hp.data(), e->posm[e->cur], k * 32, hipMemcpyDeviceToHost, e->stream));
+        NBE_HIP(hipMemcpyAsync(hv.data(), e->vel[e->cur], k * 32, hipMemcpyDeviceToHost, e->stream));
+    } else {
+        fp.resize(4 * k); fv.resize(4 * k);
+        NBE_HIP(hipMemcpyAsync(fp.data(), e->posm[e->cur], k * 16, hipMemcpyDeviceToHost, e->stream));
+        NBE_HIP(hipMemcpyAsync(fv.data(), e->vel[e->cur], k * 16, hipMemcpyDeviceToHost, e->stream));
+    }
+    NBE_HIP(hipStreamSynchronize(e->stream));
+    // a slot vacated by the last classify holds a massless body outside the bound: not a body of the run
+    double lo[3], W;
+    bound_lo(e, lo, &W);
+    size_t out = 0;
+    for (size_t i = 0; i < k; i++) {
+        const double x = e->state64 ? hp[4 * i] : (double)fp[4 * i], m = e->state64 ? hp[4 * i + 3] : (double)fp[4 * i + 3];
+        if (m == 0.0 && x == (e->state64 ? lo[0] + 2.0 * W : (double)(float)(lo[0] + 2.0 * W))) continue;
+        for (int c = 0; c < 3; c++) {
+            if (pos) pos[3 * out + c] = e->state64 ? hp[4 * i + c] : (double)fp[4 * i + c];
+            if (vel) vel[3 * out + c] = e->state64 ? hv[4 * i + c] : (double)fv[4 * i + c];
+        }
+        if (mass) mass[out] = m;
+        if (index) index[out] = ho[i];
+        out++;
+    }
+    *count = out;
+    return NBE_OK;
+}

@@ -80,6 +80,7 @@ extern "C" int nbe_create(const nbe_config* cfg, nbe_engine** out)
     }
     if (cfg->reference_quirks && cfg->mode != NBE_MODE_TREE) { nbe_set_error("reference_quirks apply to tree mode only"); return NBE_E_INVALID; }
     if (cfg->num_devices < 0) { nbe_set_error("num_devices < 0"); return NBE_E_INVALID; }
+    if (cfg->cell_sums != NBE_SUMS_PREFIX && cfg->cell_sums != NBE_SUMS_TREE) { nbe_set_error("bad cell_sums %d", cfg->cell_sums); return NBE_E_INVALID; }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
         nbe_set_error("no HIP device available (this library has no CPU path)");
@@ -132,6 +133,7 @@ extern "C" void nbe_destroy(nbe_engine* e)
     if (!e) return;
     if (e->multi) { multi_destroy(e); return; }
     (void)hipSetDevice(e->cfg.device);
+    dist_destroy(e);
     (void)frame_stream_stop(e);
     (void)hipStreamSynchronize(e->stream);
     (void)free_state(e);
@@ -159,8 +161,6 @@ extern "C" int nbe_set_stream(nbe_engine* e, void* hip_stream)
     return NBE_OK;
 }
 
-static int upload_state(nbe_engine* e, size_t n, const double* pos, const double* vel, const double* mass, const uint64_t* id);
-
 extern "C" int nbe_upload(nbe_engine* e, size_t n, const double* pos, const double* vel, const double* mass, const uint64_t* id)
 {
     if (!e) { nbe_set_error("engine is NULL"); return NBE_E_INVALID; }
@@ -171,7 +171,8 @@ extern "C" int nbe_upload(nbe_engine* e, size_t n, const double* pos, const doub
         if (!(mass[i] >= 0.0)) { nbe_set_error("mass[%zu] is negative or NaN", i); return NBE_E_INVALID; }
     if (e->multi) return multi_upload(e, n, pos, vel, mass, id);
     int rc;
-    try { rc = upload_state(e, n, pos, vel, mass, id); }
+    if (e->dist) { nbe_set_error("nbe_upload on a distributed engine; use nbe_dist_upload"); return NBE_E_INVALID; }
+    try { rc = engine_upload_state(e, n, pos, vel, mass, id); }
     catch (const std::bad_alloc&) { nbe_set_error("out of host memory"); rc = NBE_E_NOMEM; }
     if (rc != NBE_OK) {
         // leave an empty engine behind rather than half of a state (the message of the failure is kept)
@@ -184,7 +185,7 @@ extern "C" int nbe_upload(nbe_engine* e, size_t n, const double* pos, const doub
     return rc;
 }
 
-static int upload_state(nbe_engine* e, size_t n, const double* pos, const double* vel, const double* mass, const uint64_t* id)
+int engine_upload_state(nbe_engine* e, size_t n, const double* pos, const double* vel, const double* mass, const uint64_t* id)
 {
     NBE_TRY(use_device(e));
     NBE_TRY(frame_stream_stop(e));
@@ -421,6 +422,7 @@ static int force_pass(nbe_engine* e, uint64_t t0, uint64_t t1, bool fused, bool 
 // touching pairs over all pairs and replays a merging step serially, which does not shard.
 static int check_sharded_collisions(const nbe_engine* e)
 {
+    if (e->dist) { nbe_set_error("nbe_shard_* on a distributed engine; use the nbe_dist_* calls"); return NBE_E_INVALID; }
     if (e->cfg.collisions && e->cfg.mode != NBE_MODE_TREE) {
         nbe_set_error("sharded stepping supports collisions in tree mode only; use nbe_step");
         return NBE_E_UNSUPPORTED;
@@ -587,6 +589,7 @@ extern "C" int nbe_step(nbe_engine* e, int nsteps)
     if (!e) { nbe_set_error("engine is NULL"); return NBE_E_INVALID; }
     if (nsteps < 0) { nbe_set_error("nsteps < 0"); return NBE_E_INVALID; }
     if (e->multi) return multi_step(e, nsteps);
+    if (e->dist) { nbe_set_error("nbe_step on a distributed engine; use the nbe_dist_* calls"); return NBE_E_INVALID; }
     NBE_TRY(use_device(e));
     if (e->advance_pending) { nbe_set_error("nbe_step between nbe_shard_advance and nbe_shard_commit"); return NBE_E_INVALID; }
     if (e->shard_set && (e->shard_first != 0 || e->shard_count != e->n)) {

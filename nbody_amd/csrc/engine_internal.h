@@ -141,11 +141,17 @@ struct FrameStream {
     std::vector<uint64_t> ids_scratch;
 };
 
+// tw.counters slot where the sort's last pass leaves the number of live bodies, until the state has been reordered
+// (permute_kernel then publishes it in slot 0)
+#define COUNTER_SORTED_ALIVE 8
+
 struct MultiState;
+struct DistState;
 
 struct nbe_engine {
     nbe_config cfg{};
     MultiState* multi = nullptr;    // num_devices > 1: this object only coordinates one engine per GPU (multi.hip)
+    DistState* dist = nullptr;      // key-range-distributed tree (dist.hip): this engine holds one rank's bodies
     size_t n = 0;
     double equal_mass = 0.0;        // direct sum without collisions: the common mass if every body has the same, else 0
     bool state64 = false;           // fp64 state (MIXED and F64)
@@ -197,6 +203,10 @@ int multi_step(nbe_engine* e, int nsteps);
 int multi_sync(nbe_engine* e);
 int multi_set_radius(nbe_engine* e, const double* radius);
 nbe_engine* multi_first(nbe_engine* e);          // the engine of the first GPU (reads are served from it)
+// dist.hip
+void dist_destroy(nbe_engine* e);
+// engine.hip
+int engine_upload_state(nbe_engine* e, size_t n, const double* pos, const double* vel, const double* mass, const uint64_t* id);
 // direct.hip
 int direct_forces(nbe_engine* e, int src_buf, uint64_t t0, uint64_t t1, bool fused, int dst_buf);
 // tree_build.hip
@@ -204,6 +214,7 @@ int tree_workspace_reserve(nbe_engine* e);
 int tree_small_limit(void);
 int tree_sort_keys(nbe_engine* e);              // optional first half of tree_sort_and_build (reads positions only)
 int tree_sort_and_build(nbe_engine* e);         // sorts cur -> cur^1, flips e->cur, builds the tree
+int device_scan_u32(nbe_engine* e, const uint32_t* in, uint32_t* out, size_t len);
 // tree_walk.hip
 int tree_forces(nbe_engine* e, int src_buf, uint64_t t0, uint64_t t1, bool fused, bool count, int dst_buf);
 // collide.hip
@@ -211,6 +222,7 @@ int collide_workspace_reserve(nbe_engine* e);
 int collide_workspace_free(nbe_engine* e);
 int collide_fill_radius(nbe_engine* e, double* dst, double value);
 int collide_emit_nodes(nbe_engine* e);          // after the build: geometry records for the collision search
+int collide_emit_geometry(nbe_engine* e);       // key, depth and parent depth of every node only (dist.hip)
 int collide_begin(nbe_engine* e);               // first half of collide_and_update: queues the counting search, does not wait
 int collide_and_update(nbe_engine* e);          // search + merge + update of the state in e->cur into e->cur^1
 // direct_collide.hip

@@ -19,7 +19,6 @@
 
 // tw.counters[COUNTER_SORTED_ALIVE]: live bodies found by the last key sort; becomes counters[0] when the state is
 // reordered (permute_kernel)
-#define COUNTER_SORTED_ALIVE 8
 
 __device__ __forceinline__ unsigned xcd_contiguous_block(void);
 
@@ -188,28 +187,7 @@ static int device_exclusive_scan(nbe_engine* e, const uint32_t* in, uint32_t* ou
     return NBE_OK;
 }
 
-// ---- Morton keys ------------------------------------------------------------------------------------------
-// Index q in [0, 2^21) of the depth-21 cell with lo + q*cell <= x < lo + (q+1)*cell.  x - lo may round
-// across a cell boundary, so the estimate is corrected against the boundaries themselves, which are exact
-// for a power-of-two bound: the result then equals the chain of sign tests of octantBits (tree.go:128-132).
-__device__ __forceinline__ uint32_t cell_index(double x, double lo, double cell)
-{
-    double q = floor((x - lo) / cell);
-    q = fmin(fmax(q, 0.0), 2097151.0);
-    if (x < lo + q * cell && q > 0.0) q -= 1.0;
-    else if (x >= lo + (q + 1.0) * cell && q < 2097151.0) q += 1.0;
-    return (uint32_t)q;
-}
-
-// Key of one body: KEY_DEAD unless lo <= p < hi on every axis.
-__device__ __forceinline__ uint64_t body_key(double x, double y, double z, double lox, double loy, double loz, double width)
-{
-    const bool in = (lox <= x && x < lox + width) && (loy <= y && y < loy + width) && (loz <= z && z < loz + width);
-    if (!in) return KEY_DEAD;
-    const double cell = width * (1.0 / 2097152.0);    // 2^21 cells per axis at depth 21
-    return spread3(cell_index(x, lox, cell)) | (spread3(cell_index(y, loy, cell)) << 1) | (spread3(cell_index(z, loz, cell)) << 2);
-}
-
+// ---- Morton keys (cell_index and body_key: tree_keys.h) --------------------------------------------------------
 // One key per body.  A body is kept iff lo <= p < hi on every axis (contains, tree.go:65-72; NaN fails);
 // others get the all-ones key, sort to the end and stay out of the tree for good (tree.go:290-292).
 // A workgroup handles one tile of the radix sort and also counts the tile's lowest digits (the histogram of the first
@@ -586,18 +564,6 @@ __global__ __launch_bounds__(256) void radix_tree_kernel(const uint64_t* __restr
         if (cl != lvl) atomicOr(&lvlmask[gamma + 1], 1u << cl);
     }
 }
-
-// fp32 nodes store (edge / theta)^2 for the walk's one-compare opening test; theta = 0 ("always open") maps to
-// the largest float.  fp64 nodes store the edge itself.
-// With softening the walk's r^2 carries eps^2 (it is the r^2 of the force); the stored threshold of a cell carries it too,
-// so that the test still compares the bare distance with the edge and costs no subtraction per visit.
-template <typename NodeT> __device__ __forceinline__ void set_edge(NodeT& nd, double w, double theta, double eps2);
-template <> __device__ __forceinline__ void set_edge<NodeF>(NodeF& nd, double w, double theta, double eps2)
-{
-    const double q = theta > 0.0 ? (w / theta) * (w / theta) : (w > 0.0 ? 3.0e38 : 0.0);
-    nd.w2 = (float)fmin(w > 0.0 ? q + eps2 : q, 3.0e38);
-}
-template <> __device__ __forceinline__ void set_edge<NodeD>(NodeD& nd, double w, double, double) { nd.w = w; }
 
 // ---- fp64 prefix sums of (m, m*x, m*y, m*z) over the sorted bodies ---------------------------------------------
 // A cell covers a contiguous range [a, b] of sorted bodies, so its mass and first moments are differences of
@@ -1059,6 +1025,7 @@ int tree_workspace_reserve(nbe_engine* e)
     const size_t nblocks = cdiv(cap, SORT_TILE);
     w.block_hist_len = 256 * nblocks;
     size_t scan_len = w.block_hist_len > cap + 1 ? w.block_hist_len : cap + 1;
+    if (e->dist && scan_len < 2 * cap + 2) scan_len = 2 * cap + 2;       // dist.hip scans over the nodes
     w.scan_tmp_len = cdiv(scan_len, SCAN_TILE) + 1;
     if (w.scan_tmp_len < 256) w.scan_tmp_len = 256;      // also holds the 256 digit totals of a radix pass
     const size_t node_bytes = e->force64 ? sizeof(NodeD) : sizeof(NodeF);
@@ -1077,7 +1044,7 @@ int tree_workspace_reserve(nbe_engine* e)
     NBE_HIP(hipMalloc((void**)&w.cellcnt, (cap + 1) * 4));
     NBE_HIP(hipMalloc((void**)&w.nodes, (2 * cap + 2) * node_bytes));   // the walk prefetches one record past the end
     NBE_HIP(hipMemsetAsync(w.nodes, 0, (2 * cap + 2) * node_bytes, e->stream));
-    if (e->force64) {
+    if (e->force64 || e->cfg.cell_sums == NBE_SUMS_TREE) {
         NBE_HIP(hipMalloc((void**)&w.node_level, 2 * cap));
         NBE_HIP(hipMalloc((void**)&w.node_sum, 2 * cap * 4 * sizeof(double)));
     } else {
@@ -1133,7 +1100,7 @@ static int sort_keys_t(nbe_engine* e)
     return NBE_OK;
 }
 
-template <typename R4, typename S4, typename NodeT>
+template <typename R4, typename S4, typename NodeT, bool PREFIX>
 static int sort_and_build_t(nbe_engine* e)
 {
     TreeWork& w = e->tw;
@@ -1162,7 +1129,6 @@ static int sort_and_build_t(nbe_engine* e)
                        w.bt_parent, w.bt_level, w.bt_cell, w.lvlmask);
     NBE_HIP(hipGetLastError());
     NBE_TRY((device_exclusive_scan<true>(e, w.lvlmask, w.cellcnt, (size_t)n + 1)));
-    constexpr bool PREFIX = !__is_same(NodeT, NodeD);
     if (PREFIX) {
         const unsigned tiles = cdiv((size_t)n + 1, PSUM_TILE);
         if (n <= e->small_max) {
@@ -1226,9 +1192,13 @@ int tree_sort_and_build(nbe_engine* e)
     if (e->n == 0) return NBE_OK;
     if (e->n > TREE_MAX_BODIES) { nbe_set_error("tree mode supports at most 2^26 bodies"); return NBE_E_UNSUPPORTED; }
     switch (e->cfg.precision) {
-    case NBE_PREC_F32: return sort_and_build_t<float4, float4, NodeF>(e);
-    case NBE_PREC_MIXED: return sort_and_build_t<float4, double4, NodeF>(e);
-    case NBE_PREC_F64: return sort_and_build_t<double4, double4, NodeD>(e);
+    case NBE_PREC_F32:
+        return e->cfg.cell_sums == NBE_SUMS_TREE ? sort_and_build_t<float4, float4, NodeF, false>(e)
+                                                 : sort_and_build_t<float4, float4, NodeF, true>(e);
+    case NBE_PREC_MIXED:
+        return e->cfg.cell_sums == NBE_SUMS_TREE ? sort_and_build_t<float4, double4, NodeF, false>(e)
+                                                 : sort_and_build_t<float4, double4, NodeF, true>(e);
+    case NBE_PREC_F64: return sort_and_build_t<double4, double4, NodeD, false>(e);
     }
     nbe_set_error("unknown precision %d", e->cfg.precision);
     return NBE_E_INVALID;

@@ -1,0 +1,347 @@
+"""Key-range-distributed Barnes-Hut stepping: every body lives on one GPU, every GPU builds the tree of its own
+bodies, and the GPUs exchange only the bodies that change owner and the pruned subtrees the others need.
+
+The reference walks one octree of all bodies with a fan-out over workers (main.go:130-149); this module keeps that
+semantics (every body visits the nodes it would visit in the one octree, in the same order) while no GPU ever holds
+the whole octree.  The device work is in the engine (nbe_dist_* in include/nbody_engine.h, nbody_amd/csrc/dist.hip);
+this module moves the bytes: it is written once, for a list of ranks that live in this process, and a communicator
+either copies between them (LocalComm: several ranks on one GPU, for tests) or runs the collectives of
+torch.distributed (TorchComm: one rank per process, RCCL over xGMI; gloo stages through the host).
+"""
+import ctypes as C
+
+import numpy as np
+
+from .engine import Engine, EngineError, load_library
+
+try:
+    import torch
+    import torch.distributed as dist
+except Exception:  # pragma: no cover - torch is part of the image
+    torch = None
+    dist = None
+
+MAX_FRAGMENTS = 2048
+FRAGMENT = np.dtype([("key", "<u8"), ("level", "<i4"), ("start", "<i4"), ("nodes", "<i4"), ("reserved", "<i4"),
+                     ("sum", "<f8", (4,))])
+assert FRAGMENT.itemsize == 56
+
+
+class DistBuffers(C.Structure):
+    _fields_ = [("outbox", C.c_void_p), ("inbox", C.c_void_p), ("export_nodes", C.c_void_p), ("import_nodes", C.c_void_p),
+                ("slots", C.c_uint64), ("export_cap", C.c_uint64), ("import_cap", C.c_uint64),
+                ("record_bytes", C.c_uint32), ("node_bytes", C.c_uint32)]
+
+
+_declared = False
+
+
+def _declare(lib):
+    global _declared
+    if _declared:
+        return
+    vp, dp, u64p = C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)
+    lib.nbe_dist_upload.argtypes = [vp, C.c_int, C.c_int, C.c_size_t, C.c_size_t, dp, dp, dp, C.c_uint64]
+    lib.nbe_dist_sample_keys.argtypes = [vp, C.c_size_t, u64p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+    lib.nbe_dist_set_splitters.argtypes = [vp, u64p]
+    lib.nbe_dist_buffers.argtypes = [vp, C.POINTER(DistBuffers)]
+    lib.nbe_dist_classify.argtypes = [vp, C.POINTER(C.c_uint32)]
+    lib.nbe_dist_receive.argtypes = [vp, C.c_size_t]
+    lib.nbe_dist_build.argtypes = [vp, vp, C.c_int, C.POINTER(C.c_int), dp, u64p]
+    lib.nbe_dist_export.argtypes = [vp, vp, C.POINTER(C.c_int), dp, C.POINTER(C.c_int32), u64p]
+    lib.nbe_dist_assemble.argtypes = [vp, C.POINTER(C.c_int32), u64p]
+    lib.nbe_dist_advance.argtypes = [vp]
+    lib.nbe_dist_download.argtypes = [vp, u64p, dp, dp, dp, C.POINTER(C.c_size_t)]
+    for name in DIST_EXPORTS:
+        getattr(lib, name).restype = C.c_int
+    _declared = True
+
+
+DIST_EXPORTS = ["nbe_dist_upload", "nbe_dist_sample_keys", "nbe_dist_set_splitters", "nbe_dist_buffers", "nbe_dist_classify",
+                "nbe_dist_receive", "nbe_dist_build", "nbe_dist_export", "nbe_dist_assemble", "nbe_dist_advance",
+                "nbe_dist_download"]
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+class _DevicePtr:
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (int(ptr), False), "version": 3}
+
+
+class DistRank:
+    """One rank of the distributed tree: an Engine (tree mode) plus the nbe_dist_* calls."""
+
+    def __init__(self, rank, world, device=0, **engine_kw):
+        self.rank, self.world = int(rank), int(world)
+        self.engine = Engine(mode="tree", device=device, **engine_kw)
+        self._lib = load_library()
+        _declare(self._lib)
+        self._h = self.engine._h
+        self.device_index = device
+        self.capacity = 0
+        self._views = {}
+
+    def close(self):
+        self.engine.close()
+
+    def _check(self, rc):
+        self.engine._check(rc)
+
+    def upload(self, capacity, pos, vel, mass, first_index):
+        pos = np.ascontiguousarray(pos, dtype=np.float64).reshape(-1, 3)
+        vel = np.ascontiguousarray(vel, dtype=np.float64).reshape(-1, 3)
+        mass = np.ascontiguousarray(mass, dtype=np.float64).reshape(-1)
+        self._check(self._lib.nbe_dist_upload(self._h, self.rank, self.world, int(capacity), mass.shape[0], _dp(pos), _dp(vel),
+                                              _dp(mass), int(first_index)))
+        self.capacity = int(capacity)
+        self.engine.n = self.capacity
+        b = DistBuffers()
+        self._check(self._lib.nbe_dist_buffers(self._h, C.byref(b)))
+        self.buffers = b
+        self._views = {}
+
+    def use_torch_stream(self):
+        """Queue the engine's work on torch's current stream, so that it is ordered with torch's copies and collectives."""
+        self.engine.set_stream(torch.cuda.current_stream(torch.device("cuda", self.device_index)).cuda_stream)
+
+    def bytes_view(self, which):
+        """A torch uint8 tensor over one of the engine's exchange buffers (no copy)."""
+        if which not in self._views:
+            b = self.buffers
+            ptr, n = {"outbox": (b.outbox, b.slots * b.record_bytes), "inbox": (b.inbox, b.slots * b.record_bytes),
+                      "export": (b.export_nodes, b.export_cap * b.node_bytes),
+                      "import": (b.import_nodes, b.import_cap * b.node_bytes)}[which]
+            self._views[which] = torch.as_tensor(_DevicePtr(ptr, int(n)), device=torch.device("cuda", self.device_index))
+        return self._views[which]
+
+    def sample_keys(self, max_samples=4096):
+        keys = np.zeros(max_samples, dtype=np.uint64)
+        cnt, live = C.c_size_t(0), C.c_size_t(0)
+        self._check(self._lib.nbe_dist_sample_keys(self._h, max_samples, keys.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                                   C.byref(cnt), C.byref(live)))
+        return keys[:cnt.value], live.value
+
+    def set_splitters(self, split):
+        split = np.ascontiguousarray(split, dtype=np.uint64)
+        assert split.shape[0] == self.world + 1
+        self._check(self._lib.nbe_dist_set_splitters(self._h, split.ctypes.data_as(C.POINTER(C.c_uint64))))
+
+    def classify(self):
+        counts = np.zeros(self.world, dtype=np.uint32)
+        self._check(self._lib.nbe_dist_classify(self._h, counts.ctypes.data_as(C.POINTER(C.c_uint32))))
+        return counts
+
+    def receive(self, k):
+        self._check(self._lib.nbe_dist_receive(self._h, int(k)))
+
+    def build(self):
+        frags = np.zeros(MAX_FRAGMENTS, dtype=FRAGMENT)
+        cnt = C.c_int(0)
+        aabb = np.zeros(6)
+        live = C.c_uint64(0)
+        self._check(self._lib.nbe_dist_build(self._h, frags.ctypes.data, MAX_FRAGMENTS, C.byref(cnt), _dp(aabb), C.byref(live)))
+        return frags[:cnt.value].copy(), aabb, live.value
+
+    def export(self, all_frags, frag_counts, aabbs):
+        all_frags = np.ascontiguousarray(all_frags, dtype=FRAGMENT)
+        frag_counts = np.ascontiguousarray(frag_counts, dtype=np.int32)
+        aabbs = np.ascontiguousarray(aabbs, dtype=np.float64).reshape(self.world, 6)
+        nf = int(frag_counts[self.rank])
+        sizes = np.zeros((self.world, max(nf, 1)), dtype=np.int32)
+        offsets = np.zeros(self.world + 1, dtype=np.uint64)
+        self._check(self._lib.nbe_dist_export(self._h, all_frags.ctypes.data, frag_counts.ctypes.data_as(C.POINTER(C.c_int)),
+                                              _dp(aabbs), sizes.ctypes.data_as(C.POINTER(C.c_int32)),
+                                              offsets.ctypes.data_as(C.POINTER(C.c_uint64))))
+        return sizes.reshape(-1)[:self.world * nf].reshape(self.world, nf), offsets
+
+    def assemble(self, import_sizes, import_offsets):
+        import_sizes = np.ascontiguousarray(import_sizes, dtype=np.int32)
+        import_offsets = np.ascontiguousarray(import_offsets, dtype=np.uint64)
+        self._check(self._lib.nbe_dist_assemble(self._h, import_sizes.ctypes.data_as(C.POINTER(C.c_int32)),
+                                                import_offsets.ctypes.data_as(C.POINTER(C.c_uint64))))
+
+    def advance(self):
+        self._check(self._lib.nbe_dist_advance(self._h))
+
+    def download(self):
+        n = self.capacity
+        idx = np.zeros(n, dtype=np.uint64); pos = np.zeros((n, 3)); vel = np.zeros((n, 3)); mass = np.zeros(n)
+        k = C.c_size_t(0)
+        self._check(self._lib.nbe_dist_download(self._h, idx.ctypes.data_as(C.POINTER(C.c_uint64)), _dp(pos), _dp(vel), _dp(mass),
+                                                C.byref(k)))
+        k = k.value
+        return idx[:k], pos[:k], vel[:k], mass[:k]
+
+
+# ---- communicators --------------------------------------------------------------------------------------------------
+class LocalComm:
+    """All ranks live in this process (on one GPU or several): exchanges are device copies."""
+
+    def __init__(self, world):
+        self.world = world
+
+    def allgather(self, per_rank):
+        """per_rank[r] = numpy array of rank r; every rank receives the list of all of them."""
+        return [list(per_rank) for _ in range(self.world)]
+
+    def alltoall(self, ranks, which_send, which_recv, send_counts, unit):
+        """send_counts[r][q] units of `unit` bytes go from rank r's `which_send` buffer (destination after destination)
+        to rank q's `which_recv` buffer (source after source).  Returns recv_counts[q][r]."""
+        W = self.world
+        recv = [[int(send_counts[r][q]) for r in range(W)] for q in range(W)]
+        for q in range(W):
+            dst = ranks[q].bytes_view(which_recv)
+            at = 0
+            for r in range(W):
+                k = recv[q][r]
+                if k:
+                    off = int(sum(int(c) for c in send_counts[r][:q]))
+                    src = ranks[r].bytes_view(which_send)
+                    if (at + k) * unit > dst.numel():
+                        raise EngineError(f"rank {q}: the {which_recv} buffer is too small for {at + k} records")
+                    dst[at * unit:(at + k) * unit].copy_(src[off * unit:(off + k) * unit])
+                at += k
+        return recv
+
+
+class TorchComm:
+    """One rank per process under torch.distributed ("nccl" = RCCL over xGMI; "gloo" stages device buffers through
+    the host)."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.backend = dist.get_backend(group)
+        self.device = torch.device("cuda", torch.cuda.current_device()) if self.backend == "nccl" else torch.device("cpu")
+
+    def allgather(self, per_rank):
+        mine = np.ascontiguousarray(per_rank[0])
+        raw = torch.from_numpy(mine.view(np.uint8).reshape(-1).copy())
+        sizes = torch.zeros(self.world, dtype=torch.int64, device=self.device)
+        dist.all_gather_into_tensor(sizes, torch.tensor([raw.numel()], dtype=torch.int64, device=self.device), group=self.group)
+        sizes = sizes.cpu().tolist()
+        cap = max(max(sizes), 1)
+        buf = torch.zeros(cap, dtype=torch.uint8, device=self.device)
+        buf[:raw.numel()] = raw.to(self.device)
+        out = torch.zeros(self.world * cap, dtype=torch.uint8, device=self.device)
+        dist.all_gather_into_tensor(out, buf, group=self.group)
+        out = out.cpu().numpy()
+        res = []
+        for r in range(self.world):
+            a = out[r * cap:r * cap + sizes[r]].copy().view(mine.dtype)
+            res.append(a.reshape((-1,) + mine.shape[1:]) if mine.ndim > 1 else a)
+        return [res]
+
+    def alltoall(self, ranks, which_send, which_recv, send_counts, unit):
+        me = ranks[0]
+        sc = torch.tensor([int(c) for c in send_counts[0]], dtype=torch.int64, device=self.device)
+        rc = torch.zeros_like(sc)
+        dist.all_to_all_single(rc, sc, group=self.group)
+        rc = rc.cpu().tolist()
+        sc = sc.cpu().tolist()
+        src, dst = me.bytes_view(which_send), me.bytes_view(which_recv)
+        ns, nr = sum(sc) * unit, sum(rc) * unit
+        if nr > dst.numel():
+            raise EngineError(f"rank {self.rank}: the {which_recv} buffer is too small for {sum(rc)} records")
+        if self.backend == "nccl":
+            dist.all_to_all_single(dst[:nr], src[:ns], [k * unit for k in rc], [k * unit for k in sc], group=self.group)
+        else:
+            hs = src[:ns].cpu()
+            hd = torch.zeros(nr, dtype=torch.uint8)
+            dist.all_to_all_single(hd, hs, [k * unit for k in rc], [k * unit for k in sc], group=self.group)
+            dst[:nr].copy_(hd)
+        return [rc]
+
+
+def choose_splitters(samples, lives, world):
+    """Splitters from every rank's evenly spaced sorted keys: each sample of rank r stands for lives[r] / len(samples[r])
+    bodies; the k-th splitter is the key where the running weight passes k/world of all bodies.  Bodies with equal keys
+    never end up on two ranks (a splitter is a key; everything below it goes left)."""
+    keys = np.concatenate([np.asarray(s, dtype=np.uint64) for s in samples]) if samples else np.zeros(0, np.uint64)
+    w = np.concatenate([np.full(len(s), lives[r] / max(len(s), 1)) for r, s in enumerate(samples)]) if samples else np.zeros(0)
+    split = np.zeros(world + 1, dtype=np.uint64)
+    split[world] = np.uint64(1) << np.uint64(63)
+    if len(keys) == 0:
+        split[1:world] = split[world]
+        return split
+    order = np.argsort(keys, kind="stable")
+    keys, w = keys[order], w[order]
+    cum = np.cumsum(w)
+    total = cum[-1]
+    for k in range(1, world):
+        j = int(np.searchsorted(cum, total * k / world, side="left"))
+        split[k] = keys[min(j, len(keys) - 1)]
+    for k in range(1, world + 1):
+        split[k] = max(split[k], split[k - 1])
+    return split
+
+
+class DistributedTree:
+    """Steps the ranks that live in this process (all of them with LocalComm, one with TorchComm)."""
+
+    def __init__(self, ranks, comm):
+        self.ranks, self.comm = list(ranks), comm
+        self.world = comm.world
+        self.timings = None
+
+    def distribute(self, max_samples=4096):
+        """Chooses the splitters from samples of every rank's keys; the first step then moves every body to its owner."""
+        got = [r.sample_keys(max_samples) for r in self.ranks]
+        samples = self.comm.allgather([g[0] for g in got])
+        lives = self.comm.allgather([np.array([g[1]], dtype=np.int64) for g in got])
+        for k, r in enumerate(self.ranks):
+            split = choose_splitters(samples[k], [int(a[0]) for a in lives[k]], self.world)
+            r.set_splitters(split)
+        self.split = split
+        return split
+
+    def step(self, nsteps=1):
+        for _ in range(nsteps):
+            self._step()
+
+    def _step(self):
+        R, W = self.ranks, self.world
+        # bodies that crossed a splitter go to their new owner
+        send = [r.classify() for r in R]
+        unit = R[0].buffers.record_bytes
+        recv = self.comm.alltoall(R, "outbox", "inbox", send, unit)
+        for r, rc in zip(R, recv):
+            r.receive(sum(rc))
+        # every rank's own tree; the roots of its fragments and its bounding box go to everybody
+        built = [r.build() for r in R]
+        frags = self.comm.allgather([b[0] for b in built])
+        boxes = self.comm.allgather([b[1] for b in built])
+        exported = []
+        for k, r in enumerate(R):
+            counts = np.array([len(f) for f in frags[k]], dtype=np.int32)
+            allf = np.concatenate(frags[k]) if counts.sum() else np.zeros(0, dtype=FRAGMENT)
+            exported.append((r.export(allf, counts, np.stack(boxes[k])), counts))
+        # pruned fragments to those who need them, and how large each came out
+        node_bytes = R[0].buffers.node_bytes
+        sendn = [np.diff(ex[0][1].astype(np.int64)) for ex in exported]
+        recvn = self.comm.alltoall(R, "export", "import", sendn, node_bytes)
+        self.last_import_nodes = [int(sum(rc)) for rc in recvn]
+        self.last_migrated = [int(sum(rc)) for rc in recv]
+        sizes = self.comm.allgather([ex[0][0].reshape(-1) for ex in exported])
+        for k, r in enumerate(R):
+            counts = exported[k][1]
+            imp = []
+            for src in range(W):
+                nf = int(counts[src])
+                m = sizes[k][src].reshape(W, nf) if nf else np.zeros((W, 0), dtype=np.int32)
+                imp.append(m[r.rank])
+            offs = np.concatenate([[0], np.cumsum(recvn[k])[:-1]]).astype(np.uint64)
+            r.assemble(np.concatenate(imp) if len(imp) else np.zeros(0, np.int32), offs)
+        for r in R:
+            r.advance()
+
+    def download(self):
+        """(index, pos, vel, mass) of the bodies of the ranks in this process, sorted by run-wide index."""
+        parts = [r.download() for r in self.ranks]
+        idx = np.concatenate([p[0] for p in parts])
+        order = np.argsort(idx, kind="stable")
+        return tuple(np.concatenate([p[k] for p in parts])[order] for k in range(4))

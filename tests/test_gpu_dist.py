@@ -1,0 +1,154 @@
+"""The key-range-distributed tree (nbe_dist_*, nbody_amd/disttree.py): every body on one rank only, local trees,
+pruned fragments exchanged.  Checked against ONE engine stepping all bodies (whose own parity with the CPU restatement
+is the business of tests/test_gpu_tree.py): every body must visit the nodes it visits in the one octree, in the same
+order, so fp32 and fp64 runs agree bit for bit when the one engine also sums its cells child by child
+(tree_sums=True); mixed precision flushes its partial sums by wavefront and agrees to rounding."""
+import numpy as np
+import pytest
+
+from nbody_amd import Engine, EngineError, physics
+from nbody_amd.disttree import DistRank, DistributedTree, LocalComm, choose_splitters
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def run_distributed(b, world, nsteps, capacity=None, per_step=None, **kw):
+    n = len(b)
+    per = (n + world - 1) // world
+    ranks = [DistRank(r, world, **kw) for r in range(world)]
+    try:
+        for r in ranks:
+            a, z = min(n, r.rank * per), min(n, (r.rank + 1) * per)
+            r.upload(capacity or int(per * 1.5) + 1024, b.pos[a:z], b.vel[a:z], b.mass[a:z], a)
+            r.use_torch_stream()
+        dt = DistributedTree(ranks, LocalComm(world))
+        dt.distribute()
+        for s in range(nsteps):
+            dt.step(1)
+            if per_step:
+                per_step(s, dt)
+        return dt.download()
+    finally:
+        for r in ranks:
+            r.close()
+
+
+def run_one(b, nsteps, **kw):
+    with Engine(mode="tree", tree_sums=True, **kw) as e:
+        e.upload(b.pos, b.vel, b.mass)
+        e.step(nsteps)
+        p, v, m, ids = e.download()
+    return ids, p, v, m
+
+
+def test_cells_summed_child_by_child_equal_the_prefix_sums_to_rounding(gpu):
+    """NBE_SUMS_TREE on fp32 node records: the same cells, masses and centres as the default build to fp32 rounding, and
+    the centres of the pointer octree of the CPU restatement."""
+    b = physics.plummer(30000, seed=3, a=2e3)
+    tabs = []
+    for tree_sums in (False, True):
+        with Engine(mode="tree", precision="f32", theta=0.5, tree_sums=tree_sums) as e:
+            e.upload(b.pos, b.vel, b.mass)
+            tabs.append(e.tree_nodes())
+    a, t = tabs
+    assert a.shape == t.shape and np.array_equal(a[:, 4:], t[:, 4:])
+    assert np.abs(a[:, 3] - t[:, 3]).max() <= 2e-7 * a[:, 3].max()
+    assert np.abs(a[:, :3] - t[:, :3]).max() <= 2 ** -23 * 32768
+    dump, _ = O.tree_dump(b.mass.astype(np.float32).astype(np.float64), b.pos.astype(np.float32).astype(np.float64),
+                          com_mode="true", max_depth=21)
+    keep = dump[(dump["kind"] == 0) | (dump["nchild"] >= 2)]
+    assert len(keep) == len(t)
+    assert np.abs(t[:, :3] - np.stack([keep["com"][:, k] for k in range(3)], 1)).max() <= 2 ** -23 * 32768
+
+
+@pytest.mark.parametrize("n,world,precision,nsteps", [(5003, 2, "f32", 5), (5003, 3, "f32", 5), (20001, 4, "f64", 4),
+                                                      (300, 5, "f32", 4), (100000, 8, "f32", 3), (1001, 3, "f64", 6),
+                                                      (7, 3, "f32", 2)])
+def test_ranks_on_one_gpu_equal_one_engine_bit_for_bit(gpu, n, world, precision, nsteps):
+    """2 to 8 ranks (uneven n, ranks with a handful of bodies) against one engine: identical survivors, positions and
+    velocities after several steps, in which bodies change owner."""
+    b = physics.plummer(n, seed=8, a=2e3)
+    moved = []
+    got = run_distributed(b, world, nsteps, precision=precision, theta=0.6, per_step=lambda s, dt: moved.append(sum(dt.last_migrated)))
+    want = run_one(b, nsteps, precision=precision, theta=0.6)
+    assert len(got[0]) == n and np.array_equal(got[0], want[0])
+    for a, w in zip(got[1:], want[1:]):
+        assert np.array_equal(a, w)
+    if n >= 5000:
+        assert all(m > 0 for m in moved[1:])          # bodies did cross splitters after the first redistribution
+
+
+def test_softened_galaxies_and_mixed_precision(gpu):
+    """Two galaxies on approach with softening (the scene of the colliding-galaxies configuration, small): fp32 bit for
+    bit, mixed precision to the rounding of its wave-wise flushes."""
+    b = physics.galaxy_pair(6000, seed=5)
+    for precision in ("f32", "mixed"):
+        got = run_distributed(b, 4, 4, precision=precision, theta=0.5, eps=1.0)
+        want = run_one(b, 4, precision=precision, theta=0.5, eps=1.0)
+        assert np.array_equal(got[0], want[0])
+        if precision == "f32":
+            assert np.array_equal(got[1], want[1]) and np.array_equal(got[2], want[2])
+        else:
+            assert np.abs(got[1] - want[1]).max() <= 1e-9 * np.abs(want[1]).max()
+            assert np.abs(got[2] - want[2]).max() <= 1e-7 * np.abs(want[2]).max()
+
+
+def test_bodies_that_leave_the_bound_are_dropped_on_their_rank(gpu):
+    """tree.go:290-292 on a distributed run: a body that flies out is removed by its owner's next build, as one engine
+    removes it; the others carry on identically."""
+    b = physics.plummer(4000, seed=2, a=2e3)
+    pos, vel = b.pos.copy(), b.vel.copy()
+    pos[11] = (32760.0, 5.0, 5.0); vel[11] = (3.0, 0.0, 0.0)          # out through the +x face in the second step
+    pos[12] = (-32767.5, -7.0, 1.0); vel[12] = (-1.0, 0.0, 0.0)       # out through the -x face in the first step
+    bb = physics.Bodies(pos, vel, b.mass)
+    got = run_distributed(bb, 3, 5, precision="f32", theta=0.6, dt=3.0)
+    want = run_one(bb, 5, precision="f32", theta=0.6, dt=3.0)
+    assert 11 not in want[0] and 12 not in want[0] and len(want[0]) == 3998
+    assert np.array_equal(got[0], want[0])
+    for a, w in zip(got[1:], want[1:]):
+        assert np.array_equal(a, w)
+
+
+def test_call_order_and_unsupported_configurations(gpu):
+    b = physics.plummer(500, seed=1, a=2e3)
+    for kw in (dict(collisions=True), dict(per_wave=True), dict(ref_com=True)):
+        r = DistRank(0, 2, **kw)
+        with pytest.raises(EngineError, match="distributed tree needs"):
+            r.upload(1000, b.pos, b.vel, b.mass, 0)
+        r.close()
+    r = DistRank(0, 2, precision="f32")
+    try:
+        with pytest.raises(EngineError, match="nbe_dist_upload"):
+            r.classify()
+        with pytest.raises(EngineError, match="capacity"):
+            r.upload(100, b.pos, b.vel, b.mass, 0)
+        r.upload(1000, b.pos, b.vel, b.mass, 0)
+        with pytest.raises(EngineError, match="distributed engine"):
+            r.engine.step(1)
+        with pytest.raises(EngineError, match="before nbe_dist_assemble"):
+            r.advance()
+        with pytest.raises(EngineError, match="before nbe_dist_classify"):
+            r.receive(0)
+        with pytest.raises(EngineError, match="must not decrease"):
+            r.set_splitters(np.array([0, (1 << 63) + 5, 1 << 63], dtype=np.uint64))
+    finally:
+        r.close()
+
+
+def test_a_rank_that_runs_out_of_slots_says_so(gpu):
+    b = physics.plummer(4000, seed=2, a=2e3)
+    with pytest.raises(EngineError, match="slots are free|too small"):
+        # all bodies start on rank 0 and rank 1 has room for 1000
+        ranks = [DistRank(r, 2, precision="f32") for r in range(2)]
+        try:
+            ranks[0].upload(5000, b.pos, b.vel, b.mass, 0)
+            ranks[1].upload(1000, b.pos[:0], b.vel[:0], b.mass[:0], 4000)
+            for r in ranks:
+                r.use_torch_stream()
+            dt = DistributedTree(ranks, LocalComm(2))
+            dt.distribute()
+            dt.step(1)
+        finally:
+            for r in ranks:
+                r.close()
