@@ -245,6 +245,7 @@ typedef struct {
 } nbe_dist_buffers_t;
 
 #define NBE_DIST_MAX_FRAGMENTS 2048
+#define NBE_DIST_MAX_BOXES 8
 
 /* Replaces nbe_upload: the `n` bodies this rank starts with (any subset of the run's bodies; they are redistributed by
  * the first nbe_dist_classify), in an engine with room for `capacity` >= n bodies.  `first_index` numbers them:
@@ -262,14 +263,17 @@ int nbe_dist_buffers(nbe_engine *e, nbe_dist_buffers_t *out);
 int nbe_dist_classify(nbe_engine *e, uint32_t *send_counts);
 /* Takes over the first k records of the inbox. */
 int nbe_dist_receive(nbe_engine *e, size_t k);
-/* Sorts the rank's bodies, builds its tree and lists its fragments in key order (at most `max`); aabb = min x,y,z and
- * max x,y,z of its bodies.  Synchronises. */
-int nbe_dist_build(nbe_engine *e, nbe_fragment_t *frags, int max, int *count, double aabb[6], uint64_t *n_live);
-/* all_frags: the fragments of rank 0, then rank 1, ... (frag_counts[r] each); aabbs: world x 6.  Writes the pruned
- * fragments for every other rank into export_nodes; export_offsets[d] .. export_offsets[d+1] are the nodes for rank d,
- * export_sizes[d * frag_counts[rank] + f] the nodes of this rank's fragment f in there.  Synchronises. */
-int nbe_dist_export(nbe_engine *e, const nbe_fragment_t *all_frags, const int *frag_counts, const double *aabbs,
-                    int32_t *export_sizes, uint64_t *export_offsets);
+/* Sorts the rank's bodies, builds its tree and lists its fragments in key order (at most `max`).  boxes: up to
+ * NBE_DIST_MAX_BOXES bounding boxes (min x,y,z, max x,y,z) that together hold the rank's bodies: a key range is a union of
+ * cells that can lie far apart, so the fragments are grouped into runs that share a small cell and every run gets the box of
+ * its bodies.  Synchronises. */
+int nbe_dist_build(nbe_engine *e, nbe_fragment_t *frags, int max, int *count, double *boxes, int *nboxes, uint64_t *n_live);
+/* all_frags: the fragments of rank 0, then rank 1, ... (frag_counts[r] each); boxes: world x NBE_DIST_MAX_BOXES x 6, of
+ * which the first box_counts[r] of rank r count.  Writes the pruned fragments for every other rank into export_nodes;
+ * export_offsets[d] .. export_offsets[d+1] are the nodes for rank d, export_sizes[d * frag_counts[rank] + f] the nodes of
+ * this rank's fragment f in there.  Synchronises. */
+int nbe_dist_export(nbe_engine *e, const nbe_fragment_t *all_frags, const int *frag_counts, const double *boxes,
+                    const int *box_counts, int32_t *export_sizes, uint64_t *export_offsets);
 /* import_sizes: for every rank r in turn, the sizes its frag_counts[r] fragments have in its export to this rank (this
  * rank's own entries are ignored); import_offsets[r]: where rank r's export starts in import_nodes, in nodes. */
 int nbe_dist_assemble(nbe_engine *e, const int32_t *import_sizes, const uint64_t *import_offsets);

@@ -40,6 +40,8 @@ struct TopCell {          // a cell that spans ranks
     double sum[4];
 };
 
+#define BOX_PARTS 64      // workgroups that share the bodies of one box
+
 struct DistState {
     int rank = 0, world = 1;
     size_t cap = 0;                     // body slots of this engine (== e->n)
@@ -58,8 +60,9 @@ struct DistState {
     int* d_nfrag = nullptr;             // [0] count, [1] overflow flag of the export buffer
     nbe_fragment_t* h_frags = nullptr;  // pinned
     int* h_small = nullptr;             // pinned scratch: counters and sizes
-    double* d_aabb = nullptr;           // partial boxes [1024][6] then the final [6]
-    double* h_aabb = nullptr;           // pinned [6]
+    double* d_aabb = nullptr;           // [MAX_BOXES][6] boxes, then [MAX_BOXES][BOX_PARTS][6] partial ones
+    double* h_aabb = nullptr;           // pinned [MAX_BOXES][6]
+    uint64_t* d_groups = nullptr;       // [MAX_BOXES][2] first and last key of the runs of fragments that share a box
     std::vector<nbe_fragment_t> my_frags;          // sorted by key
     std::vector<nbe_fragment_t> all_frags;         // rank after rank
     std::vector<int> frag_counts;
@@ -72,7 +75,8 @@ struct DistState {
     size_t export_cap = 0;
     unsigned long long* d_export_base = nullptr;   // world + 1 running node offsets
     int* d_export_sizes = nullptr;      // world x NBE_DIST_MAX_FRAGMENTS
-    double* d_boxes = nullptr;          // world x 6
+    double* d_boxes = nullptr;          // world x MAX_BOXES x 6
+    int* d_box_counts = nullptr;        // world
     // import + assembled array
     void* import_nodes = nullptr;
     size_t import_cap = 0;
@@ -97,7 +101,7 @@ void dist_destroy(nbe_engine* e)
     void** dev[] = {(void**)&d->d_split, (void**)&d->d_counts, &d->outbox, &d->inbox, (void**)&d->free_slots, (void**)&d->d_frags,
                     (void**)&d->d_nfrag, (void**)&d->d_aabb, (void**)&d->x_diff, (void**)&d->x_cover, (void**)&d->x_flag,
                     (void**)&d->x_index, &d->export_nodes, (void**)&d->d_export_base, (void**)&d->d_export_sizes,
-                    (void**)&d->d_boxes, &d->import_nodes, &d->let_nodes, (void**)&d->let_counters, (void**)&d->d_segments,
+                    (void**)&d->d_boxes, (void**)&d->d_box_counts, (void**)&d->d_groups, &d->import_nodes, &d->let_nodes, (void**)&d->let_counters, (void**)&d->d_segments,
                     (void**)&d->d_top};
     for (void** p : dev) (void)dfree(p);
     void* host[] = {d->h_counts, d->h_frags, d->h_small, d->h_aabb};
@@ -184,8 +188,9 @@ extern "C" int nbe_dist_upload(nbe_engine* e, int rank, int world, size_t capaci
     NBE_HIP(hipMalloc((void**)&d->d_nfrag, 2 * sizeof(int)));
     NBE_HIP(hipHostMalloc((void**)&d->h_frags, NBE_DIST_MAX_FRAGMENTS * sizeof(nbe_fragment_t), hipHostMallocDefault));
     NBE_HIP(hipHostMalloc((void**)&d->h_small, (16 + (W2 + 1) * 2 + W2 * NBE_DIST_MAX_FRAGMENTS) * sizeof(int), hipHostMallocDefault));
-    NBE_HIP(hipMalloc((void**)&d->d_aabb, (1024 + 1) * 6 * sizeof(double)));
-    NBE_HIP(hipHostMalloc((void**)&d->h_aabb, 6 * sizeof(double), hipHostMallocDefault));
+    NBE_HIP(hipMalloc((void**)&d->d_aabb, (size_t)NBE_DIST_MAX_BOXES * (BOX_PARTS + 1) * 6 * sizeof(double)));
+    NBE_HIP(hipHostMalloc((void**)&d->h_aabb, NBE_DIST_MAX_BOXES * 6 * sizeof(double), hipHostMallocDefault));
+    NBE_HIP(hipMalloc((void**)&d->d_groups, NBE_DIST_MAX_BOXES * 2 * sizeof(uint64_t)));
     NBE_HIP(hipMalloc((void**)&d->x_diff, nodes2 * 4));
     NBE_HIP(hipMalloc((void**)&d->x_cover, nodes2 * 4));
     NBE_HIP(hipMalloc((void**)&d->x_flag, nodes2 * 4));
@@ -204,7 +209,8 @@ extern "C" int nbe_dist_upload(nbe_engine* e, int rank, int world, size_t capaci
     NBE_HIP(hipMemsetAsync(d->let_counters, 0, 16 * sizeof(int), e->stream));
     NBE_HIP(hipMalloc((void**)&d->d_export_base, (W2 + 1) * sizeof(unsigned long long)));
     NBE_HIP(hipMalloc((void**)&d->d_export_sizes, W2 * NBE_DIST_MAX_FRAGMENTS * sizeof(int)));
-    NBE_HIP(hipMalloc((void**)&d->d_boxes, W2 * 6 * sizeof(double)));
+    NBE_HIP(hipMalloc((void**)&d->d_boxes, W2 * NBE_DIST_MAX_BOXES * 6 * sizeof(double)));
+    NBE_HIP(hipMalloc((void**)&d->d_box_counts, W2 * sizeof(int)));
     d->seg_cap = W2 * NBE_DIST_MAX_FRAGMENTS;
     d->top_cap = W2 * NBE_DIST_MAX_FRAGMENTS;
     NBE_HIP(hipMalloc((void**)&d->d_segments, d->seg_cap * sizeof(Segment)));
@@ -473,12 +479,23 @@ __global__ __launch_bounds__(256) void fragments_kernel(const CNode* __restrict_
     frags[at] = f;
 }
 
+// Box of the bodies whose keys lie in [groups[2g], groups[2g+1]]: BOX_PARTS workgroups share the run, then one reduces.
 template <typename R4>
-__global__ __launch_bounds__(256) void aabb_partial_kernel(const R4* __restrict__ pos, const int* __restrict__ counters, double* __restrict__ part)
+__global__ __launch_bounds__(256) void box_partial_kernel(const R4* __restrict__ pos, const uint64_t* __restrict__ keys,
+                                                          const int* __restrict__ counters, const uint64_t* __restrict__ groups,
+                                                          double* __restrict__ part)
 {
     const int na = counters[0];
+    const int g = blockIdx.y;
+    const uint64_t kmin = groups[2 * g], kmax = groups[2 * g + 1];
+    int lo = 0, hi = na;                              // first body with key >= kmin
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (keys[mid] < kmin) lo = mid + 1; else hi = mid; }
+    const int first = lo;
+    hi = na;                                          // first body with key > kmax
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (keys[mid] <= kmax) lo = mid + 1; else hi = mid; }
+    const int last = lo;
     double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < na; i += gridDim.x * 256) {
+    for (int i = first + blockIdx.x * 256 + threadIdx.x; i < last; i += BOX_PARTS * 256) {
         const R4 p = pos[i];
         const double v[3] = {(double)p.x, (double)p.y, (double)p.z};
         for (int c = 0; c < 3; c++) { mn[c] = fmin(mn[c], v[c]); mx[c] = fmax(mx[c], v[c]); }
@@ -494,23 +511,62 @@ __global__ __launch_bounds__(256) void aabb_partial_kernel(const R4* __restrict_
             }
         __syncthreads();
     }
-    if (threadIdx.x < 6) part[blockIdx.x * 6 + threadIdx.x] = s[threadIdx.x][0];
+    if (threadIdx.x < 6) part[((size_t)g * BOX_PARTS + blockIdx.x) * 6 + threadIdx.x] = s[threadIdx.x][0];
 }
 
-__global__ __launch_bounds__(64) void aabb_final_kernel(const double* __restrict__ part, int nparts, double* __restrict__ out)
+__global__ __launch_bounds__(64) void box_final_kernel(const double* __restrict__ part, double* __restrict__ out)
 {
-    const int c = threadIdx.x;
+    const int g = blockIdx.x, c = threadIdx.x;
     if (c >= 6) return;
     double v = c < 3 ? INFINITY : -INFINITY;
-    for (int b = 0; b < nparts; b++) v = c < 3 ? fmin(v, part[b * 6 + c]) : fmax(v, part[b * 6 + c]);
-    out[c] = v;
+    for (int b = 0; b < BOX_PARTS; b++) {
+        const double x = part[((size_t)g * BOX_PARTS + b) * 6 + c];
+        v = c < 3 ? fmin(v, x) : fmax(v, x);
+    }
+    out[g * 6 + c] = v;
 }
 
-extern "C" int nbe_dist_build(nbe_engine* e, nbe_fragment_t* frags, int max, int* count, double aabb[6], uint64_t* n_live)
+// Depth of the smallest cell that holds both keys (63-bit keys, 3 bits per level).
+static int common_level(uint64_t a, uint64_t b)
+{
+    if (a == b) return 21;
+    const int d = __builtin_clzll(a ^ b) - 1;
+    const int l = d / 3;
+    return l > 21 ? 21 : l;
+}
+
+// The rank's key range is a union of cells that may lie far apart (a range that crosses the middle of the bound holds
+// the end of one octant and the start of the next), so one box around all its bodies can span the bound.  The fragments,
+// in key order, are merged into at most NBE_DIST_MAX_BOXES runs: always the two neighbours that share the deepest cell.
+static void group_fragments(const std::vector<nbe_fragment_t>& fr, std::vector<uint64_t>* groups)
+{
+    struct Run { uint64_t kmin, kmax; };
+    std::vector<Run> runs;
+    for (const nbe_fragment_t& f : fr) {
+        if (f.level >= 21) { runs.push_back(Run{f.key, f.key}); continue; }
+        const uint64_t size = 1ull << (3 * (21 - f.level));
+        const uint64_t cmin = f.key & ~(size - 1ull);
+        runs.push_back(Run{cmin, cmin + (size - 1ull)});
+    }
+    while (runs.size() > (size_t)NBE_DIST_MAX_BOXES) {
+        size_t best = 0;
+        int best_level = -1;
+        for (size_t i = 0; i + 1 < runs.size(); i++) {
+            const int l = common_level(runs[i].kmin, runs[i + 1].kmax);
+            if (l > best_level) { best_level = l; best = i; }
+        }
+        runs[best].kmax = runs[best + 1].kmax;
+        runs.erase(runs.begin() + (long)best + 1);
+    }
+    groups->clear();
+    for (const Run& r : runs) { groups->push_back(r.kmin); groups->push_back(r.kmax); }
+}
+
+extern "C" int nbe_dist_build(nbe_engine* e, nbe_fragment_t* frags, int max, int* count, double* boxes, int* nboxes, uint64_t* n_live)
 {
     NBE_TRY(check_dist(e, "nbe_dist_build"));
     DistState* d = e->dist;
-    if (!frags || !count || !aabb) { nbe_set_error("NULL argument"); return NBE_E_INVALID; }
+    if (!frags || !count || !boxes || !nboxes) { nbe_set_error("NULL argument"); return NBE_E_INVALID; }
     e->keys_sorted = false;
     NBE_TRY(tree_sort_and_build(e));
     NBE_TRY(collide_emit_geometry(e));
@@ -518,19 +574,10 @@ extern "C" int nbe_dist_build(nbe_engine* e, nbe_fragment_t* frags, int max, int
     const size_t n = e->n;
     hipLaunchKernelGGL(fragments_kernel, dim3(cdiv(2 * n, 256)), dim3(256), 0, e->stream, e->cw.cnodes, e->tw.counters, e->tw.node_sum,
                        d->split[d->rank], d->split[d->rank + 1], d->d_frags, d->d_nfrag);
-    const int parts = (int)std::min<size_t>(1024, cdiv(n, 256));
-    if (e->cfg.precision == NBE_PREC_F64)
-        hipLaunchKernelGGL((aabb_partial_kernel<double4>), dim3(parts), dim3(256), 0, e->stream, (const double4*)key_positions(e),
-                           e->tw.counters, d->d_aabb + 6);
-    else
-        hipLaunchKernelGGL((aabb_partial_kernel<float4>), dim3(parts), dim3(256), 0, e->stream, (const float4*)key_positions(e),
-                           e->tw.counters, d->d_aabb + 6);
-    hipLaunchKernelGGL(aabb_final_kernel, dim3(1), dim3(64), 0, e->stream, d->d_aabb + 6, parts, d->d_aabb);
     NBE_HIP(hipGetLastError());
     NBE_HIP(hipMemcpyAsync(d->h_small, e->tw.counters, 4 * sizeof(int), hipMemcpyDeviceToHost, e->stream));
     NBE_HIP(hipMemcpyAsync(d->h_small + 4, d->d_nfrag, sizeof(int), hipMemcpyDeviceToHost, e->stream));
     NBE_HIP(hipMemcpyAsync(d->h_frags, d->d_frags, NBE_DIST_MAX_FRAGMENTS * sizeof(nbe_fragment_t), hipMemcpyDeviceToHost, e->stream));
-    NBE_HIP(hipMemcpyAsync(d->h_aabb, d->d_aabb, 6 * sizeof(double), hipMemcpyDeviceToHost, e->stream));
     NBE_HIP(hipStreamSynchronize(e->stream));
     const int na = d->h_small[0], nf = d->h_small[4];
     if (nf > NBE_DIST_MAX_FRAGMENTS || nf > max) { nbe_set_error("rank %d has %d fragments (limit %d)", d->rank, nf, std::min(max, NBE_DIST_MAX_FRAGMENTS)); return NBE_E_UNSUPPORTED; }
@@ -538,7 +585,26 @@ extern "C" int nbe_dist_build(nbe_engine* e, nbe_fragment_t* frags, int max, int
     std::sort(d->my_frags.begin(), d->my_frags.end(), [](const nbe_fragment_t& a, const nbe_fragment_t& b) { return a.key < b.key; });
     if (nf) memcpy(frags, d->my_frags.data(), (size_t)nf * sizeof(nbe_fragment_t));
     *count = nf;
-    memcpy(aabb, d->h_aabb, 6 * sizeof(double));
+    // the boxes of the rank's bodies, one per run of fragments
+    std::vector<uint64_t> groups;
+    group_fragments(d->my_frags, &groups);
+    const int nb = (int)(groups.size() / 2);
+    if (nb > 0) {
+        NBE_HIP(hipMemcpyAsync(d->d_groups, groups.data(), groups.size() * sizeof(uint64_t), hipMemcpyHostToDevice, e->stream));
+        double* part = d->d_aabb + NBE_DIST_MAX_BOXES * 6;
+        if (e->cfg.precision == NBE_PREC_F64)
+            hipLaunchKernelGGL((box_partial_kernel<double4>), dim3(BOX_PARTS, nb), dim3(256), 0, e->stream, (const double4*)key_positions(e),
+                               e->tw.keys[0], e->tw.counters, d->d_groups, part);
+        else
+            hipLaunchKernelGGL((box_partial_kernel<float4>), dim3(BOX_PARTS, nb), dim3(256), 0, e->stream, (const float4*)key_positions(e),
+                               e->tw.keys[0], e->tw.counters, d->d_groups, part);
+        hipLaunchKernelGGL(box_final_kernel, dim3(nb), dim3(64), 0, e->stream, part, d->d_aabb);
+        NBE_HIP(hipGetLastError());
+        NBE_HIP(hipMemcpyAsync(d->h_aabb, d->d_aabb, (size_t)nb * 6 * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+        NBE_HIP(hipStreamSynchronize(e->stream));
+        memcpy(boxes, d->h_aabb, (size_t)nb * 6 * sizeof(double));
+    }
+    *nboxes = nb;
     if (n_live) *n_live = (uint64_t)na;
     d->live_hi = (size_t)na;          // the sort has packed the live bodies into the first slots
     d->n_free = 0;
@@ -562,17 +628,23 @@ __device__ __forceinline__ double box_distance(double x, double y, double z, con
     const double dx = fmax(fmax(b[0] - x, x - b[3]), 0.0), dy = fmax(fmax(b[1] - y, y - b[4]), 0.0), dz = fmax(fmax(b[2] - z, z - b[5]), 0.0);
     return sqrt(dx * dx + dy * dy + dz * dz);
 }
-__device__ __forceinline__ bool may_open(const NodeF& nd, const double* __restrict__ box, double theta, double eps2, double slack, double rel)
+__device__ __forceinline__ bool may_open(const NodeF& nd, const double* __restrict__ boxes, int nboxes, double theta, double eps2, double slack, double rel)
 {
     if (!(nd.w2 > 0.0f)) return false;                // a body: never opened
-    const double dlow = fmax(box_distance((double)nd.x, (double)nd.y, (double)nd.z, box) - slack, 0.0);
-    return dlow * dlow * (1.0 - rel) < (double)nd.w2 * (1.0 + rel);      // (eps^2 left out on the left: errs towards "may open")
+    for (int b = 0; b < nboxes; b++) {
+        const double dlow = fmax(box_distance((double)nd.x, (double)nd.y, (double)nd.z, boxes + 6 * b) - slack, 0.0);
+        if (dlow * dlow * (1.0 - rel) < (double)nd.w2 * (1.0 + rel)) return true;      // (eps^2 left out on the left: errs towards "may open")
+    }
+    return false;
 }
-__device__ __forceinline__ bool may_open(const NodeD& nd, const double* __restrict__ box, double theta, double, double slack, double rel)
+__device__ __forceinline__ bool may_open(const NodeD& nd, const double* __restrict__ boxes, int nboxes, double theta, double, double slack, double rel)
 {
     if (!(nd.w > 0.0)) return false;
-    const double dlow = fmax(box_distance(nd.x, nd.y, nd.z, box) - slack, 0.0);
-    return nd.w * nd.w * (1.0 + rel) >= theta * theta * dlow * dlow * (1.0 - rel);
+    for (int b = 0; b < nboxes; b++) {
+        const double dlow = fmax(box_distance(nd.x, nd.y, nd.z, boxes + 6 * b) - slack, 0.0);
+        if (nd.w * nd.w * (1.0 + rel) >= theta * theta * dlow * dlow * (1.0 - rel)) return true;
+    }
+    return false;
 }
 
 // Cells inside the rank's key range that the box cannot open hide everything below them: +1 on the node after, -1 on
@@ -580,15 +652,16 @@ __device__ __forceinline__ bool may_open(const NodeD& nd, const double* __restri
 template <typename NodeT>
 __global__ __launch_bounds__(256) void export_mark_kernel(const NodeT* __restrict__ nodes, const CNode* __restrict__ cn,
                                                           const int* __restrict__ counters, uint64_t lo, uint64_t hi,
-                                                          const double* __restrict__ box, double theta, double eps2, double slack,
-                                                          double rel, uint32_t* __restrict__ diff)
+                                                          const double* __restrict__ boxes, const int* __restrict__ nboxes,
+                                                          double theta, double eps2, double slack, double rel,
+                                                          uint32_t* __restrict__ diff)
 {
     const int total = counters[1];
     const int p = blockIdx.x * 256 + threadIdx.x;
     if (p >= total) return;
     const CNode c = cn[p];
     if (c.body >= 0 || !cell_inside(c.key, c.level, lo, hi)) return;
-    if (may_open(nodes[p], box, theta, eps2, slack, rel)) return;
+    if (may_open(nodes[p], boxes, *nboxes, theta, eps2, slack, rel)) return;
     atomicAdd(&diff[p + 1], 1u);
     atomicAdd(&diff[c.skip], 0xffffffffu);
 }
@@ -665,7 +738,8 @@ static int export_t(nbe_engine* e, int32_t* export_sizes, uint64_t* export_offse
         }
         NBE_HIP(hipMemsetAsync(d->x_diff, 0, (2 * n + 2) * 4, e->stream));
         hipLaunchKernelGGL((export_mark_kernel<NodeT>), dim3(grid), dim3(256), 0, e->stream, (const NodeT*)e->tw.nodes, e->cw.cnodes,
-                           e->tw.counters, lo, hi, d->d_boxes + 6 * (size_t)q, e->cfg.theta, eps2, slack, rel, d->x_diff);
+                           e->tw.counters, lo, hi, d->d_boxes + 6 * (size_t)NBE_DIST_MAX_BOXES * q, d->d_box_counts + q, e->cfg.theta, eps2,
+                           slack, rel, d->x_diff);
         NBE_TRY(device_scan_u32(e, d->x_diff, d->x_cover, 2 * n + 2));
         hipLaunchKernelGGL(export_flag_kernel, dim3(grid), dim3(256), 0, e->stream, e->cw.cnodes, e->tw.counters, lo, hi, d->x_cover, d->x_flag);
         NBE_TRY(device_scan_u32(e, d->x_flag, d->x_index, 2 * n + 2));
@@ -693,12 +767,14 @@ static int export_t(nbe_engine* e, int32_t* export_sizes, uint64_t* export_offse
     return NBE_OK;
 }
 
-extern "C" int nbe_dist_export(nbe_engine* e, const nbe_fragment_t* all_frags, const int* frag_counts, const double* aabbs,
-                               int32_t* export_sizes, uint64_t* export_offsets)
+extern "C" int nbe_dist_export(nbe_engine* e, const nbe_fragment_t* all_frags, const int* frag_counts, const double* boxes,
+                               const int* box_counts, int32_t* export_sizes, uint64_t* export_offsets)
 {
     NBE_TRY(check_dist(e, "nbe_dist_export"));
     DistState* d = e->dist;
-    if (!frag_counts || !aabbs || !export_sizes || !export_offsets) { nbe_set_error("NULL argument"); return NBE_E_INVALID; }
+    if (!frag_counts || !boxes || !box_counts || !export_sizes || !export_offsets) { nbe_set_error("NULL argument"); return NBE_E_INVALID; }
+    for (int r = 0; r < d->world; r++)
+        if (box_counts[r] < 0 || box_counts[r] > NBE_DIST_MAX_BOXES) { nbe_set_error("bad box count of rank %d", r); return NBE_E_INVALID; }
     if (!d->built) { nbe_set_error("nbe_dist_export before nbe_dist_build"); return NBE_E_INVALID; }
     size_t total = 0;
     for (int r = 0; r < d->world; r++) {
@@ -709,7 +785,8 @@ extern "C" int nbe_dist_export(nbe_engine* e, const nbe_fragment_t* all_frags, c
     if (total > 0 && !all_frags) { nbe_set_error("all_frags is NULL"); return NBE_E_INVALID; }
     d->all_frags.assign(all_frags, all_frags + total);
     d->frag_counts.assign(frag_counts, frag_counts + d->world);
-    NBE_HIP(hipMemcpyAsync(d->d_boxes, aabbs, (size_t)d->world * 6 * sizeof(double), hipMemcpyHostToDevice, e->stream));
+    NBE_HIP(hipMemcpyAsync(d->d_boxes, boxes, (size_t)d->world * NBE_DIST_MAX_BOXES * 6 * sizeof(double), hipMemcpyHostToDevice, e->stream));
+    NBE_HIP(hipMemcpyAsync(d->d_box_counts, box_counts, (size_t)d->world * sizeof(int), hipMemcpyHostToDevice, e->stream));
     NBE_HIP(hipMemsetAsync(d->let_counters + 8, 0, 2 * sizeof(int), e->stream));
     NBE_HIP(hipMemsetAsync(d->x_index, 0, 4, e->stream));
     int rc = e->force64 ? export_t<NodeD>(e, export_sizes, export_offsets) : export_t<NodeF>(e, export_sizes, export_offsets);
@@ -725,15 +802,6 @@ struct Layout {
     std::vector<TopCell> tops;
     int total = 0;
 };
-
-// Depth of the smallest cell that holds both keys (63-bit keys, 3 bits per level).
-static int common_level(uint64_t a, uint64_t b)
-{
-    if (a == b) return 21;
-    const int d = __builtin_clzll(a ^ b) - 1;
-    const int l = d / 3;
-    return l > 21 ? 21 : l;
-}
 
 // Lays out fragments [i, j), which share a cell, in pre-order from index `at`; returns the number of nodes and leaves the
 // fp64 sums of what it laid out in `sum`.  A cell sums its children in octant order starting from zero, as cell_mass_kernel.

@@ -22,6 +22,7 @@ except Exception:  # pragma: no cover - torch is part of the image
     dist = None
 
 MAX_FRAGMENTS = 2048
+MAX_BOXES = 8
 FRAGMENT = np.dtype([("key", "<u8"), ("level", "<i4"), ("start", "<i4"), ("nodes", "<i4"), ("reserved", "<i4"),
                      ("sum", "<f8", (4,))])
 assert FRAGMENT.itemsize == 56
@@ -47,8 +48,8 @@ def _declare(lib):
     lib.nbe_dist_buffers.argtypes = [vp, C.POINTER(DistBuffers)]
     lib.nbe_dist_classify.argtypes = [vp, C.POINTER(C.c_uint32)]
     lib.nbe_dist_receive.argtypes = [vp, C.c_size_t]
-    lib.nbe_dist_build.argtypes = [vp, vp, C.c_int, C.POINTER(C.c_int), dp, u64p]
-    lib.nbe_dist_export.argtypes = [vp, vp, C.POINTER(C.c_int), dp, C.POINTER(C.c_int32), u64p]
+    lib.nbe_dist_build.argtypes = [vp, vp, C.c_int, C.POINTER(C.c_int), dp, C.POINTER(C.c_int), u64p]
+    lib.nbe_dist_export.argtypes = [vp, vp, C.POINTER(C.c_int), dp, C.POINTER(C.c_int), C.POINTER(C.c_int32), u64p]
     lib.nbe_dist_assemble.argtypes = [vp, C.POINTER(C.c_int32), u64p]
     lib.nbe_dist_advance.argtypes = [vp]
     lib.nbe_dist_download.argtypes = [vp, u64p, dp, dp, dp, C.POINTER(C.c_size_t)]
@@ -139,21 +140,29 @@ class DistRank:
 
     def build(self):
         frags = np.zeros(MAX_FRAGMENTS, dtype=FRAGMENT)
-        cnt = C.c_int(0)
-        aabb = np.zeros(6)
+        cnt, nb = C.c_int(0), C.c_int(0)
+        boxes = np.zeros((MAX_BOXES, 6))
         live = C.c_uint64(0)
-        self._check(self._lib.nbe_dist_build(self._h, frags.ctypes.data, MAX_FRAGMENTS, C.byref(cnt), _dp(aabb), C.byref(live)))
-        return frags[:cnt.value].copy(), aabb, live.value
+        self._check(self._lib.nbe_dist_build(self._h, frags.ctypes.data, MAX_FRAGMENTS, C.byref(cnt), _dp(boxes), C.byref(nb),
+                                             C.byref(live)))
+        return frags[:cnt.value].copy(), boxes[:nb.value].copy(), live.value
 
-    def export(self, all_frags, frag_counts, aabbs):
+    def export(self, all_frags, frag_counts, boxes):
+        """boxes: per rank, its [k, 6] boxes."""
         all_frags = np.ascontiguousarray(all_frags, dtype=FRAGMENT)
         frag_counts = np.ascontiguousarray(frag_counts, dtype=np.int32)
-        aabbs = np.ascontiguousarray(aabbs, dtype=np.float64).reshape(self.world, 6)
+        padded = np.zeros((self.world, MAX_BOXES, 6))
+        box_counts = np.zeros(self.world, dtype=np.int32)
+        for r, bx in enumerate(boxes):
+            bx = np.asarray(bx, dtype=np.float64).reshape(-1, 6)
+            padded[r, :len(bx)] = bx
+            box_counts[r] = len(bx)
         nf = int(frag_counts[self.rank])
         sizes = np.zeros((self.world, max(nf, 1)), dtype=np.int32)
         offsets = np.zeros(self.world + 1, dtype=np.uint64)
         self._check(self._lib.nbe_dist_export(self._h, all_frags.ctypes.data, frag_counts.ctypes.data_as(C.POINTER(C.c_int)),
-                                              _dp(aabbs), sizes.ctypes.data_as(C.POINTER(C.c_int32)),
+                                              _dp(padded), box_counts.ctypes.data_as(C.POINTER(C.c_int)),
+                                              sizes.ctypes.data_as(C.POINTER(C.c_int32)),
                                               offsets.ctypes.data_as(C.POINTER(C.c_uint64))))
         return sizes.reshape(-1)[:self.world * nf].reshape(self.world, nf), offsets
 
@@ -319,7 +328,7 @@ class DistributedTree:
         for k, r in enumerate(R):
             counts = np.array([len(f) for f in frags[k]], dtype=np.int32)
             allf = np.concatenate(frags[k]) if counts.sum() else np.zeros(0, dtype=FRAGMENT)
-            exported.append((r.export(allf, counts, np.stack(boxes[k])), counts))
+            exported.append((r.export(allf, counts, boxes[k]), counts))
         # pruned fragments to those who need them, and how large each came out
         node_bytes = R[0].buffers.node_bytes
         sendn = [np.diff(ex[0][1].astype(np.int64)) for ex in exported]
