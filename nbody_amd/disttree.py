@@ -312,16 +312,39 @@ class DistributedTree:
         for _ in range(nsteps):
             self._step()
 
+    def step_profiled(self):
+        """One step with the device drained after every phase: returns the wall-clock milliseconds of each phase summed
+        over the ranks of this process (with LocalComm, divide by their number for what one GPU of a real run does)."""
+        import time
+        self.timings = {}
+        self._t0 = time.perf_counter()
+        self._step()
+        t = self.timings
+        self.timings = None
+        return t
+
+    def _mark(self, name):
+        if self.timings is None:
+            return
+        import time
+        torch.cuda.synchronize()
+        now = time.perf_counter()
+        self.timings[name] = self.timings.get(name, 0.0) + (now - self._t0) * 1e3
+        self._t0 = now
+
     def _step(self):
         R, W = self.ranks, self.world
         # bodies that crossed a splitter go to their new owner
         send = [r.classify() for r in R]
+        self._mark("classify")
         unit = R[0].buffers.record_bytes
         recv = self.comm.alltoall(R, "outbox", "inbox", send, unit)
         for r, rc in zip(R, recv):
             r.receive(sum(rc))
+        self._mark("migrate")
         # every rank's own tree; the roots of its fragments and its bounding box go to everybody
         built = [r.build() for r in R]
+        self._mark("sort_build")
         frags = self.comm.allgather([b[0] for b in built])
         boxes = self.comm.allgather([b[1] for b in built])
         exported = []
@@ -329,6 +352,7 @@ class DistributedTree:
             counts = np.array([len(f) for f in frags[k]], dtype=np.int32)
             allf = np.concatenate(frags[k]) if counts.sum() else np.zeros(0, dtype=FRAGMENT)
             exported.append((r.export(allf, counts, boxes[k]), counts))
+        self._mark("export")
         # pruned fragments to those who need them, and how large each came out
         node_bytes = R[0].buffers.node_bytes
         sendn = [np.diff(ex[0][1].astype(np.int64)) for ex in exported]
@@ -345,8 +369,10 @@ class DistributedTree:
                 imp.append(m[r.rank])
             offs = np.concatenate([[0], np.cumsum(recvn[k])[:-1]]).astype(np.uint64)
             r.assemble(np.concatenate(imp) if len(imp) else np.zeros(0, np.int32), offs)
+        self._mark("exchange_assemble")
         for r in R:
             r.advance()
+        self._mark("walk")
 
     def download(self):
         """(index, pos, vel, mass) of the bodies of the ranks in this process, sorted by run-wide index."""

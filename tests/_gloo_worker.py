@@ -83,6 +83,24 @@ def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo", rank=rank, world_size=world)
     bodies = physics.makebodies(n - 2, seed=11)
+    if kind == "dist":
+        # key-range-distributed tree: this rank starts with its slice of the upload order, all ranks share cuda:0
+        from nbody_amd.disttree import DistRank, DistributedTree, TorchComm
+        prec = sys.argv[6]
+        per = (n + world - 1) // world
+        a, z = min(n, rank * per), min(n, (rank + 1) * per)
+        r = DistRank(rank, world, precision=prec, theta=0.5)
+        r.upload(int(per * 1.5) + 1024, bodies.pos[a:z], bodies.vel[a:z], bodies.mass[a:z], a)
+        r.use_torch_stream()
+        dt = DistributedTree([r], TorchComm())
+        dt.distribute()
+        dt.step(nsteps)
+        idx, pos, vel, mass = dt.download()
+        np.savez(f"{out_prefix}.rank{rank}.npz", pos=pos, vel=vel, mass=mass, ids=idx)
+        r.close()
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     if kind == "oracle":
         shard = OracleShard(bodies, mode, 0.5, 3600.0, collisions="collide" in sys.argv[6:])
         # the CPU stand-in has no wavefronts to align the ranges with; "split" as a seventh argument rehearses the

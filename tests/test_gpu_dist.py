@@ -152,3 +152,21 @@ def test_a_rank_that_runs_out_of_slots_says_so(gpu):
         finally:
             for r in ranks:
                 r.close()
+
+
+@pytest.mark.parametrize("world,precision", [(2, "f32"), (3, "f64")])
+def test_one_process_per_rank_over_torch_distributed(gpu, tmp_path, world, precision):
+    """The same stepper with one rank per process and the exchanges as torch.distributed collectives (gloo here, all
+    ranks on cuda:0; "nccl" = RCCL takes the same path with device buffers): together the ranks hold what one engine
+    reaches, bit for bit."""
+    from tests.test_sharded_gloo import run_ranks
+    n = 6001
+    res = run_ranks(tmp_path, world, ["tree", str(n), "4", "dist", precision], timeout=240)
+    b = physics.makebodies(n - 2, seed=11)
+    want = run_one(b, 4, precision=precision, theta=0.5)
+    ids = np.concatenate([r["ids"] for r in res])
+    order = np.argsort(ids)
+    assert np.array_equal(ids[order], want[0])
+    assert all(len(r["ids"]) > 0 for r in res)
+    for name, w in (("pos", want[1]), ("vel", want[2]), ("mass", want[3])):
+        assert np.array_equal(np.concatenate([r[name] for r in res])[order], w), name
