@@ -256,6 +256,67 @@ def main():
                 acc = {k: float(v) for k, v in zip(sorted(acc), t.tolist())}
             extra["bh_theta0.5_fp32_plummer_16M"]["sharded_phase_ms"] = acc
         e3.close()
+        # The same cloud and the same per-body walk with the key-range-distributed tree (nbe_dist_*): every body resident
+        # on one GPU, every GPU sorts and builds its own N/G bodies, pruned subtrees are exchanged.
+        from nbody_amd.disttree import DistRank, DistributedTree, LocalComm, TorchComm
+        b = physics.plummer(m, seed=1)
+
+        def dist_ranks(nranks, mine):
+            per = (m + nranks - 1) // nranks
+            out = []
+            for r in mine:
+                dr = DistRank(r, nranks, device=local, precision="f32", theta=0.5)
+                dr.upload(int(per * 1.25) + 4096, b.pos[r * per:(r + 1) * per], b.vel[r * per:(r + 1) * per], b.mass[r * per:(r + 1) * per], r * per)
+                dr.use_torch_stream()
+                out.append(dr)
+            return out
+
+        if world > 1 or force_dist:
+            ranks = dist_ranks(world, [rank])
+            tree = DistributedTree(ranks, TorchComm())
+            tree.distribute()
+            sec = timed_steps(lambda: tree.step(1), sync, barrier, 2, 5)      # (the first step moves every body to its owner)
+            acc = {}
+            for _ in range(3):
+                for k, v in tree.step_profiled().items():
+                    acc[k] = acc.get(k, 0.0) + v / 3
+            live = float(ranks[0].engine.stats().n_alive)
+            if world > 1:
+                t = torch.tensor([sec] + [acc[k] for k in sorted(acc)], device="cuda", dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                sec = float(t[0].item())
+                acc = {k: float(v) for k, v in zip(sorted(acc), t[1:].tolist())}
+                t = torch.tensor([live, -live], device="cuda", dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                live = [float(t[0].item()), -float(t[1].item())]
+            extra["bh_theta0.5_fp32_plummer_16M_distributed_tree"] = {
+                "steps_per_s": 5 / sec, "ms_per_step": 1e3 * sec / 5, "phase_ms_max_over_ranks": acc,
+                "bodies_per_rank_max_min": live, "imported_nodes_this_rank": tree.last_import_nodes[0],
+                "migrated_bodies_this_rank": tree.last_migrated[0]}
+            for r in ranks:
+                r.close()
+        else:
+            # one GPU: eight ranks side by side on it, phases drained one by one; a rank's share of the sums is what a GPU
+            # of an eight-GPU run does per step (the exchanges are device copies here)
+            nr = 8
+            ranks = dist_ranks(nr, range(nr))
+            tree = DistributedTree(ranks, LocalComm(nr))
+            tree.distribute()
+            tree.step(2)
+            acc = {}
+            for _ in range(3):
+                for k, v in tree.step_profiled().items():
+                    acc[k] = acc.get(k, 0.0) + v / 3
+            per_rank = {k: v / nr for k, v in acc.items()}
+            one = extra["bh_theta0.5_fp32_plummer_16M"]["ms_per_step"]
+            extra["bh_theta0.5_fp32_plummer_16M_distributed_tree_8_ranks_on_one_gpu"] = {
+                "phase_ms_sum_over_ranks": acc, "phase_ms_per_rank": per_rank, "ms_per_step_per_rank": sum(per_rank.values()),
+                "one_gpu_ms_per_step": one, "ratio_one_gpu_step_to_rank_step": one / sum(per_rank.values()),
+                "imported_nodes_per_rank": tree.last_import_nodes, "migrated_bodies_per_rank": tree.last_migrated,
+                "bodies_per_rank": [int(r.engine.stats().n_alive) for r in ranks]}
+            for r in ranks:
+                r.close()
+        del b
         # the same cloud with the opening test taken per wavefront of 128 bodies (finer than the reference's per-body
         # test, not its interaction set; off by default), also on every GPU count
         e3w, s3w = run("tree", m, "f32", 0.5, 5, 1, per_wave=True)

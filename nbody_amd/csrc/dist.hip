@@ -41,6 +41,7 @@ struct TopCell {          // a cell that spans ranks
 };
 
 #define BOX_PARTS 64      // workgroups that share the bodies of one box
+#define EXPORT_BATCH 8    // destinations whose exports are made by the same launches
 
 struct DistState {
     int rank = 0, world = 1;
@@ -67,13 +68,13 @@ struct DistState {
     std::vector<nbe_fragment_t> all_frags;         // rank after rank
     std::vector<int> frag_counts;
     // export
-    uint32_t* x_diff = nullptr;         // 2 cap + 2 each
+    uint32_t* x_diff = nullptr;         // (2 cap + 2) per destination of a batch, + 1
     uint32_t* x_cover = nullptr;
     uint32_t* x_flag = nullptr;
     uint32_t* x_index = nullptr;
     void* export_nodes = nullptr;
     size_t export_cap = 0;
-    unsigned long long* d_export_base = nullptr;   // world + 1 running node offsets
+    unsigned long long* d_export_base = nullptr;   // [0, world] first exported node per destination and the end; then two batch bases
     int* d_export_sizes = nullptr;      // world x NBE_DIST_MAX_FRAGMENTS
     double* d_boxes = nullptr;          // world x MAX_BOXES x 6
     int* d_box_counts = nullptr;        // world
@@ -191,10 +192,11 @@ extern "C" int nbe_dist_upload(nbe_engine* e, int rank, int world, size_t capaci
     NBE_HIP(hipMalloc((void**)&d->d_aabb, (size_t)NBE_DIST_MAX_BOXES * (BOX_PARTS + 1) * 6 * sizeof(double)));
     NBE_HIP(hipHostMalloc((void**)&d->h_aabb, NBE_DIST_MAX_BOXES * 6 * sizeof(double), hipHostMallocDefault));
     NBE_HIP(hipMalloc((void**)&d->d_groups, NBE_DIST_MAX_BOXES * 2 * sizeof(uint64_t)));
-    NBE_HIP(hipMalloc((void**)&d->x_diff, nodes2 * 4));
-    NBE_HIP(hipMalloc((void**)&d->x_cover, nodes2 * 4));
-    NBE_HIP(hipMalloc((void**)&d->x_flag, nodes2 * 4));
-    NBE_HIP(hipMalloc((void**)&d->x_index, nodes2 * 4));
+    const size_t xlen = nodes2 * (W2 > EXPORT_BATCH ? (size_t)EXPORT_BATCH : (W2 > 1 ? W2 - 1 : 1)) + 1;
+    NBE_HIP(hipMalloc((void**)&d->x_diff, xlen * 4));
+    NBE_HIP(hipMalloc((void**)&d->x_cover, xlen * 4));
+    NBE_HIP(hipMalloc((void**)&d->x_flag, xlen * 4));
+    NBE_HIP(hipMalloc((void**)&d->x_index, xlen * 4));
     // With few bodies per rank every other rank needs most of a rank's tree; with many, a small part of it.
     const size_t others = W2 > 5 ? 4 : (W2 > 1 ? W2 - 1 : 1);
     d->export_cap = nodes2 * others;
@@ -207,7 +209,7 @@ extern "C" int nbe_dist_upload(nbe_engine* e, int rank, int world, size_t capaci
     NBE_HIP(hipMemsetAsync(d->let_nodes, 0, (d->let_cap + 2) * node_bytes, e->stream));
     NBE_HIP(hipMalloc((void**)&d->let_counters, 16 * sizeof(int)));
     NBE_HIP(hipMemsetAsync(d->let_counters, 0, 16 * sizeof(int), e->stream));
-    NBE_HIP(hipMalloc((void**)&d->d_export_base, (W2 + 1) * sizeof(unsigned long long)));
+    NBE_HIP(hipMalloc((void**)&d->d_export_base, (W2 + 3) * sizeof(unsigned long long)));
     NBE_HIP(hipMalloc((void**)&d->d_export_sizes, W2 * NBE_DIST_MAX_FRAGMENTS * sizeof(int)));
     NBE_HIP(hipMalloc((void**)&d->d_boxes, W2 * NBE_DIST_MAX_BOXES * 6 * sizeof(double)));
     NBE_HIP(hipMalloc((void**)&d->d_box_counts, W2 * sizeof(int)));
@@ -261,7 +263,9 @@ extern "C" int nbe_dist_sample_keys(nbe_engine* e, size_t max_samples, uint64_t*
     NBE_TRY(check_dist(e, "nbe_dist_sample_keys"));
     DistState* d = e->dist;
     if (!keys_out || !count) { nbe_set_error("NULL argument"); return NBE_E_INVALID; }
-    if (max_samples > d->cap) max_samples = d->cap;
+    e->n = d->live_hi;                                // only the slots that can hold bodies (see nbe_dist_build)
+    if (max_samples > e->n) max_samples = e->n;
+    if (max_samples == 0) { *count = 0; if (n_live) *n_live = 0; return NBE_OK; }
     e->keys_sorted = false;
     NBE_TRY(tree_sort_keys(e));                       // keys of the current state, sorted, in tw.keys[0]
     e->keys_sorted = false;                           // (the state changes before the build: it sorts again)
@@ -568,12 +572,18 @@ extern "C" int nbe_dist_build(nbe_engine* e, nbe_fragment_t* frags, int max, int
     DistState* d = e->dist;
     if (!frags || !count || !boxes || !nboxes) { nbe_set_error("NULL argument"); return NBE_E_INVALID; }
     e->keys_sorted = false;
-    NBE_TRY(tree_sort_and_build(e));
-    NBE_TRY(collide_emit_geometry(e));
+    // Only the slots that can hold bodies take part: the engine's body count is the number of those (its buffers keep
+    // their capacity), so the sort, the build and the walk do not pay for the free slots behind them.
+    e->n = d->live_hi;
     NBE_HIP(hipMemsetAsync(d->d_nfrag, 0, 2 * sizeof(int), e->stream));
-    const size_t n = e->n;
-    hipLaunchKernelGGL(fragments_kernel, dim3(cdiv(2 * n, 256)), dim3(256), 0, e->stream, e->cw.cnodes, e->tw.counters, e->tw.node_sum,
-                       d->split[d->rank], d->split[d->rank + 1], d->d_frags, d->d_nfrag);
+    if (e->n == 0) {
+        NBE_HIP(hipMemsetAsync(e->tw.counters, 0, 16 * sizeof(int), e->stream));
+    } else {
+        NBE_TRY(tree_sort_and_build(e));
+        NBE_TRY(collide_emit_geometry(e));
+        hipLaunchKernelGGL(fragments_kernel, dim3(cdiv(2 * e->n, 256)), dim3(256), 0, e->stream, e->cw.cnodes, e->tw.counters,
+                           e->tw.node_sum, d->split[d->rank], d->split[d->rank + 1], d->d_frags, d->d_nfrag);
+    }
     NBE_HIP(hipGetLastError());
     NBE_HIP(hipMemcpyAsync(d->h_small, e->tw.counters, 4 * sizeof(int), hipMemcpyDeviceToHost, e->stream));
     NBE_HIP(hipMemcpyAsync(d->h_small + 4, d->d_nfrag, sizeof(int), hipMemcpyDeviceToHost, e->stream));
@@ -647,67 +657,96 @@ __device__ __forceinline__ bool may_open(const NodeD& nd, const double* __restri
     return false;
 }
 
-// Cells inside the rank's key range that the box cannot open hide everything below them: +1 on the node after, -1 on
-// the node after their subtree; the running sum is then the number of such cells above a node.
+// The destinations are handled EXPORT_BATCH at a time: destination j of a batch owns elements [j*L, (j+1)*L) of the
+// work arrays (L = 2n + 2 >= nodes + 1), so one launch and one device-wide scan serve the whole batch.
+struct DestList { int q[EXPORT_BATCH]; int n; };
+
+// Cells inside the rank's key range that a destination's boxes cannot open hide everything below them: +1 on the node
+// after, -1 on the node after their subtree; the running sum is then the number of such cells above a node.  (The +1
+// and -1 of a cell fall into the same destination's stretch, so every stretch sums to zero and the running sum of the
+// concatenated array is that of each stretch.)
 template <typename NodeT>
 __global__ __launch_bounds__(256) void export_mark_kernel(const NodeT* __restrict__ nodes, const CNode* __restrict__ cn,
                                                           const int* __restrict__ counters, uint64_t lo, uint64_t hi,
                                                           const double* __restrict__ boxes, const int* __restrict__ nboxes,
-                                                          double theta, double eps2, double slack, double rel,
-                                                          uint32_t* __restrict__ diff)
+                                                          DestList dests, size_t L, double theta, double eps2, double slack,
+                                                          double rel, uint32_t* __restrict__ diff)
 {
     const int total = counters[1];
     const int p = blockIdx.x * 256 + threadIdx.x;
     if (p >= total) return;
     const CNode c = cn[p];
     if (c.body >= 0 || !cell_inside(c.key, c.level, lo, hi)) return;
-    if (may_open(nodes[p], boxes, *nboxes, theta, eps2, slack, rel)) return;
-    atomicAdd(&diff[p + 1], 1u);
-    atomicAdd(&diff[c.skip], 0xffffffffu);
+    const NodeT nd = nodes[p];
+    for (int j = 0; j < dests.n; j++) {
+        const int q = dests.q[j];
+        if (may_open(nd, boxes + 6 * (size_t)NBE_DIST_MAX_BOXES * q, nboxes[q], theta, eps2, slack, rel)) continue;
+        atomicAdd(&diff[j * L + p + 1], 1u);
+        atomicAdd(&diff[j * L + c.skip], 0xffffffffu);
+    }
 }
 
-// cover = exclusive scan of diff: cover[p + 1] is the running sum up to and including p.
+// cover = exclusive scan of diff: cover[j*L + p + 1] is the running sum up to and including node p.  A node goes to
+// destination j iff it belongs to a fragment (its cell is inside the key range) and nothing above it hides it.
 __global__ __launch_bounds__(256) void export_flag_kernel(const CNode* __restrict__ cn, const int* __restrict__ counters, uint64_t lo,
-                                                          uint64_t hi, const uint32_t* __restrict__ cover, uint32_t* __restrict__ flag)
+                                                          uint64_t hi, const uint32_t* __restrict__ cover, size_t L, int ndest,
+                                                          uint32_t* __restrict__ flag)
 {
     const int total = counters[1];
-    const int p = blockIdx.x * 256 + threadIdx.x;
-    if (p > total) return;
-    if (p == total) { flag[p] = 0; return; }
-    const CNode c = cn[p];
-    const bool in = c.body >= 0 || cell_inside(c.key, c.level, lo, hi);
-    flag[p] = (in && cover[p + 1] == 0u) ? 1u : 0u;
+    const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int j = blockIdx.y;
+    if (p == 0 && j == 0) flag[(size_t)ndest * L] = 0;      // the scan's last element: the total of the batch
+    if (p >= L) return;
+    uint32_t v = 0;
+    if (p < (size_t)total) {
+        const CNode c = cn[p];
+        const bool in = c.body >= 0 || cell_inside(c.key, c.level, lo, hi);
+        v = (in && cover[j * L + p + 1] == 0u) ? 1u : 0u;
+    }
+    flag[j * L + p] = v;
 }
 
-// base[dest + 1] = base[dest] + exported nodes; sizes of the fragments in this export; flags an overflow of the buffer.
-__global__ __launch_bounds__(256) void export_sizes_kernel(const int* __restrict__ counters, const uint32_t* __restrict__ index,
-                                                           const nbe_fragment_t* __restrict__ frags, int nfrag, int dest,
-                                                           unsigned long long* __restrict__ base, unsigned long long cap,
+// index = exclusive scan of flag over the whole batch: index[j*L + p] counts the nodes exported before node p of
+// destination j, those of the batch's earlier destinations included, i.e. the node's place behind the batch's base.
+// Leaves the destinations' first nodes in base[q], the sizes of the fragments in there, and the next batch's base.
+__global__ __launch_bounds__(256) void export_sizes_kernel(const uint32_t* __restrict__ index, const nbe_fragment_t* __restrict__ frags,
+                                                           int nfrag, DestList dests, size_t L, unsigned long long* __restrict__ base,
+                                                           int world, const unsigned long long* __restrict__ batch_base,
+                                                           unsigned long long* __restrict__ next_base, unsigned long long cap,
                                                            int* __restrict__ sizes, int* __restrict__ overflow)
 {
-    const int total = counters[1];
     const int f = blockIdx.x * 256 + threadIdx.x;
+    const int j = blockIdx.y;
+    const int q = dests.q[j];
     if (f == 0) {
-        const unsigned long long nb = base[dest] + index[total];
-        base[dest + 1] = nb;
-        if (nb > cap) *overflow = 1;
+        base[q] = *batch_base + index[j * L];
+        if (j == dests.n - 1) {
+            const unsigned long long end = *batch_base + index[(size_t)dests.n * L];
+            *next_base = end;
+            base[world] = end;
+            if (end > cap) *overflow = 1;
+        }
     }
-    if (f < nfrag) sizes[f] = (int)(index[frags[f].start + frags[f].nodes] - index[frags[f].start]);
+    if (f < nfrag)
+        sizes[(size_t)q * NBE_DIST_MAX_FRAGMENTS + f] =
+            (int)(index[j * L + frags[f].start + frags[f].nodes] - index[j * L + frags[f].start]);
 }
 
 template <typename NodeT>
 __global__ __launch_bounds__(256) void export_write_kernel(const NodeT* __restrict__ nodes, const int* __restrict__ counters,
                                                            const uint32_t* __restrict__ flag, const uint32_t* __restrict__ index,
-                                                           const unsigned long long* __restrict__ base, int dest, unsigned long long cap,
+                                                           size_t L, const unsigned long long* __restrict__ batch_base,
+                                                           const unsigned long long* __restrict__ next_base, unsigned long long cap,
                                                            NodeT* __restrict__ out)
 {
     const int total = counters[1];
     const int p = blockIdx.x * 256 + threadIdx.x;
-    if (p >= total || !flag[p]) return;
-    if (base[dest + 1] > cap) return;                 // overflow: reported by the host, nothing written
+    const int j = blockIdx.y;
+    if (p >= total || !flag[j * L + p]) return;
+    if (*next_base > cap) return;                     // overflow: reported by the host, nothing written
     NodeT nd = nodes[p];
-    nd.skip = (int)index[nd.skip];                    // relative to the first node of this export
-    out[base[dest] + index[p]] = nd;
+    nd.skip = (int)(index[j * L + nd.skip] - index[j * L]);      // relative to the first node of this destination's export
+    out[*batch_base + index[j * L + p]] = nd;
 }
 
 template <typename NodeT>
@@ -717,7 +756,7 @@ static int export_t(nbe_engine* e, int32_t* export_sizes, uint64_t* export_offse
     const int W = d->world;
     const int nf = (int)d->my_frags.size();
     const size_t n = e->n;
-    const unsigned grid = cdiv(2 * n + 1, 256);
+    const size_t L = 2 * n + 2;
     const uint64_t lo = d->split[d->rank], hi = d->split[d->rank + 1];
     const double eps2 = e->cfg.eps * e->cfg.eps;
     // rounding of a body's own distance: its coordinates and the node's are within the bound (|x| <= |centre| + width),
@@ -726,28 +765,35 @@ static int export_t(nbe_engine* e, int32_t* export_sizes, uint64_t* export_offse
     for (int c = 0; c < 3; c++) reach = fmax(reach, fabs(e->cfg.bound_center[c]) + e->cfg.bound_width);
     const double ulp = e->force64 ? 2.3e-16 : 1.2e-7;
     const double slack = 4.0 * ulp * reach, rel = 16.0 * ulp;
-    NBE_HIP(hipMemsetAsync(d->d_export_base, 0, sizeof(unsigned long long), e->stream));
+    unsigned long long* batch_base = d->d_export_base + (W + 1);      // two device scalars used in turn
+    NBE_HIP(hipMemsetAsync(d->d_export_base, 0, (size_t)(W + 3) * sizeof(unsigned long long), e->stream));
     NBE_HIP(hipMemsetAsync(d->d_nfrag + 1, 0, sizeof(int), e->stream));
-    NBE_HIP(hipMemcpyAsync(d->d_frags, d->my_frags.data(), (size_t)nf * sizeof(nbe_fragment_t), hipMemcpyHostToDevice, e->stream));
-    for (int q = 0; q < W; q++) {
-        if (q == d->rank || nf == 0) {               // nothing goes to oneself
-            hipLaunchKernelGGL(export_sizes_kernel, dim3(1), dim3(256), 0, e->stream, d->let_counters + 8, d->x_index, d->d_frags, 0, q,
-                               d->d_export_base, (unsigned long long)d->export_cap, d->d_export_sizes + (size_t)q * NBE_DIST_MAX_FRAGMENTS,
-                               d->d_nfrag + 1);      // (counters[1] = 0 and index[0] = 0 there: adds nothing)
-            continue;
-        }
-        NBE_HIP(hipMemsetAsync(d->x_diff, 0, (2 * n + 2) * 4, e->stream));
-        hipLaunchKernelGGL((export_mark_kernel<NodeT>), dim3(grid), dim3(256), 0, e->stream, (const NodeT*)e->tw.nodes, e->cw.cnodes,
-                           e->tw.counters, lo, hi, d->d_boxes + 6 * (size_t)NBE_DIST_MAX_BOXES * q, d->d_box_counts + q, e->cfg.theta, eps2,
-                           slack, rel, d->x_diff);
-        NBE_TRY(device_scan_u32(e, d->x_diff, d->x_cover, 2 * n + 2));
-        hipLaunchKernelGGL(export_flag_kernel, dim3(grid), dim3(256), 0, e->stream, e->cw.cnodes, e->tw.counters, lo, hi, d->x_cover, d->x_flag);
-        NBE_TRY(device_scan_u32(e, d->x_flag, d->x_index, 2 * n + 2));
-        hipLaunchKernelGGL(export_sizes_kernel, dim3(cdiv(nf, 256)), dim3(256), 0, e->stream, e->tw.counters, d->x_index, d->d_frags, nf, q,
-                           d->d_export_base, (unsigned long long)d->export_cap, d->d_export_sizes + (size_t)q * NBE_DIST_MAX_FRAGMENTS,
-                           d->d_nfrag + 1);
-        hipLaunchKernelGGL((export_write_kernel<NodeT>), dim3(grid), dim3(256), 0, e->stream, (const NodeT*)e->tw.nodes, e->tw.counters,
-                           d->x_flag, d->x_index, d->d_export_base, q, (unsigned long long)d->export_cap, (NodeT*)d->export_nodes);
+    NBE_HIP(hipMemsetAsync(d->d_export_sizes, 0, (size_t)W * NBE_DIST_MAX_FRAGMENTS * sizeof(int), e->stream));
+    if (nf) NBE_HIP(hipMemcpyAsync(d->d_frags, d->my_frags.data(), (size_t)nf * sizeof(nbe_fragment_t), hipMemcpyHostToDevice, e->stream));
+    std::vector<int> others;
+    for (int q = 0; q < W; q++)
+        if (q != d->rank) others.push_back(q);
+    int batch = 0;
+    for (size_t at = 0; nf > 0 && at < others.size(); at += EXPORT_BATCH, batch++) {
+        DestList dl;
+        dl.n = (int)std::min<size_t>(EXPORT_BATCH, others.size() - at);
+        for (int j = 0; j < EXPORT_BATCH; j++) dl.q[j] = j < dl.n ? others[at + (size_t)j] : 0;
+        const size_t len = (size_t)dl.n * L;
+        const unsigned long long* cur_base = batch_base + (batch & 1);
+        unsigned long long* nxt_base = batch_base + ((batch + 1) & 1);
+        NBE_HIP(hipMemsetAsync(d->x_diff, 0, len * 4, e->stream));
+        hipLaunchKernelGGL((export_mark_kernel<NodeT>), dim3(cdiv(2 * n, 256)), dim3(256), 0, e->stream, (const NodeT*)e->tw.nodes,
+                           e->cw.cnodes, e->tw.counters, lo, hi, d->d_boxes, d->d_box_counts, dl, L, e->cfg.theta, eps2, slack, rel,
+                           d->x_diff);
+        NBE_TRY(device_scan_u32(e, d->x_diff, d->x_cover, len));
+        hipLaunchKernelGGL(export_flag_kernel, dim3(cdiv(L, 256), dl.n), dim3(256), 0, e->stream, e->cw.cnodes, e->tw.counters, lo, hi,
+                           d->x_cover, L, dl.n, d->x_flag);
+        NBE_TRY(device_scan_u32(e, d->x_flag, d->x_index, len + 1));
+        hipLaunchKernelGGL(export_sizes_kernel, dim3(cdiv(nf, 256), dl.n), dim3(256), 0, e->stream, d->x_index, d->d_frags, nf, dl, L,
+                           d->d_export_base, W, cur_base, nxt_base, (unsigned long long)d->export_cap, d->d_export_sizes, d->d_nfrag + 1);
+        hipLaunchKernelGGL((export_write_kernel<NodeT>), dim3(cdiv(2 * n, 256), dl.n), dim3(256), 0, e->stream, (const NodeT*)e->tw.nodes,
+                           e->tw.counters, d->x_flag, d->x_index, L, cur_base, nxt_base, (unsigned long long)d->export_cap,
+                           (NodeT*)d->export_nodes);
         NBE_HIP(hipGetLastError());
     }
     // read back: offsets, overflow flag, sizes
@@ -761,7 +807,9 @@ static int export_t(nbe_engine* e, int32_t* export_sizes, uint64_t* export_offse
                                    hipMemcpyDeviceToHost, e->stream));
     NBE_HIP(hipStreamSynchronize(e->stream));
     if (d->h_small[1]) { nbe_set_error("rank %d: the export buffer (%zu nodes) is too small", d->rank, d->export_cap); return NBE_E_NOMEM; }
-    for (int q = 0; q <= W; q++) export_offsets[q] = (uint64_t)h_base[q];
+    // destinations were written in rank order; a rank that gets nothing (this one) starts where the next one starts
+    export_offsets[W] = (uint64_t)h_base[W];
+    for (int q = W - 1; q >= 0; q--) export_offsets[q] = (q == d->rank || nf == 0) ? export_offsets[q + 1] : (uint64_t)h_base[q];
     for (int q = 0; q < W; q++)
         for (int f = 0; f < nf; f++) export_sizes[(size_t)q * nf + f] = q == d->rank ? 0 : h_sizes[(size_t)q * nf + f];
     return NBE_OK;
@@ -787,8 +835,6 @@ extern "C" int nbe_dist_export(nbe_engine* e, const nbe_fragment_t* all_frags, c
     d->frag_counts.assign(frag_counts, frag_counts + d->world);
     NBE_HIP(hipMemcpyAsync(d->d_boxes, boxes, (size_t)d->world * NBE_DIST_MAX_BOXES * 6 * sizeof(double), hipMemcpyHostToDevice, e->stream));
     NBE_HIP(hipMemcpyAsync(d->d_box_counts, box_counts, (size_t)d->world * sizeof(int), hipMemcpyHostToDevice, e->stream));
-    NBE_HIP(hipMemsetAsync(d->let_counters + 8, 0, 2 * sizeof(int), e->stream));
-    NBE_HIP(hipMemsetAsync(d->x_index, 0, 4, e->stream));
     int rc = e->force64 ? export_t<NodeD>(e, export_sizes, export_offsets) : export_t<NodeF>(e, export_sizes, export_offsets);
     if (rc == NBE_OK) d->exported = true;
     return rc;

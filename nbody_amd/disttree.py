@@ -317,6 +317,7 @@ class DistributedTree:
         over the ranks of this process (with LocalComm, divide by their number for what one GPU of a real run does)."""
         import time
         self.timings = {}
+        torch.cuda.synchronize()
         self._t0 = time.perf_counter()
         self._step()
         t = self.timings
