@@ -277,6 +277,16 @@ int nbe_dist_export(nbe_engine *e, const nbe_fragment_t *all_frags, const int *f
 /* import_sizes: for every rank r in turn, the sizes its frag_counts[r] fragments have in its export to this rank (this
  * rank's own entries are ignored); import_offsets[r]: where rank r's export starts in import_nodes, in nodes. */
 int nbe_dist_assemble(nbe_engine *e, const int32_t *import_sizes, const uint64_t *import_offsets);
+/* The host-side half of nbe_dist_assemble on its own (needs no GPU and no engine; for tests of the stitching): given the
+ * fragments of all ranks in key order and the number of nodes each occupies, lays out the global pre-order.  tops receives
+ * the cells that span fragments (first index, index after the subtree, depth, fp64 sums of the children added in octant
+ * order), frag_dst the first index of every fragment, *total the number of nodes. */
+typedef struct {
+    int32_t dst, skip, level, reserved;
+    double sum[4];
+} nbe_dist_top_cell_t;
+int nbe_dist_layout(const nbe_fragment_t *all_frags, int nfrags, const int32_t *sizes, nbe_dist_top_cell_t *tops, int max_tops,
+                    int *ntops, int32_t *frag_dst, int64_t *total);
 /* Force pass over the assembled node array + fused update of the rank's bodies (main.go:130-149, 171-177). */
 int nbe_dist_advance(nbe_engine *e);
 /* The rank's live bodies: run-wide index, position, velocity, mass (any pointer may be NULL). */

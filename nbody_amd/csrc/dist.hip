@@ -882,6 +882,33 @@ static int layout_range(const std::vector<FragRef>& fr, int i, int j, int at, co
     return n;
 }
 
+extern "C" int nbe_dist_layout(const nbe_fragment_t* all_frags, int nfrags, const int32_t* sizes, nbe_dist_top_cell_t* tops, int max_tops,
+                               int* ntops, int32_t* frag_dst, int64_t* total)
+{
+    if (nfrags < 0 || (nfrags > 0 && (!all_frags || !sizes)) || !ntops || !total) { nbe_set_error("nbe_dist_layout: bad argument"); return NBE_E_INVALID; }
+    std::vector<FragRef> fr;
+    std::vector<Segment> seg_of;
+    for (int g = 0; g < nfrags; g++) {
+        if (g > 0 && !(all_frags[g - 1].key < all_frags[g].key)) { nbe_set_error("fragments are not in key order (at %d)", g); return NBE_E_INVALID; }
+        if (sizes[g] < 1) { nbe_set_error("fragment %d has no nodes", g); return NBE_E_INVALID; }
+        fr.push_back(FragRef{all_frags[g].key, 0, g, sizes[g], all_frags[g].sum});
+        seg_of.push_back(Segment{0, sizes[g], g, 0, 0});          // src carries the fragment's number
+    }
+    Layout lay;
+    double sum[4];
+    if (!fr.empty()) lay.total = layout_range(fr, 0, nfrags, 0, seg_of, &lay, sum);
+    *total = lay.total;
+    *ntops = (int)lay.tops.size();
+    if ((int)lay.tops.size() > max_tops && tops) { nbe_set_error("%zu spanning cells, room for %d", lay.tops.size(), max_tops); return NBE_E_INVALID; }
+    for (size_t t = 0; tops && t < lay.tops.size(); t++) {
+        tops[t].dst = lay.tops[t].dst; tops[t].skip = lay.tops[t].skip; tops[t].level = lay.tops[t].level; tops[t].reserved = 0;
+        for (int k = 0; k < 4; k++) tops[t].sum[k] = lay.tops[t].sum[k];
+    }
+    if (frag_dst)
+        for (const Segment& s : lay.segs) frag_dst[s.src] = s.dst;
+    return NBE_OK;
+}
+
 template <typename NodeT>
 __global__ __launch_bounds__(256) void top_cells_kernel(const TopCell* __restrict__ tops, int ntops, double bound_width, double theta,
                                                         double eps2, int total, NodeT* __restrict__ out)

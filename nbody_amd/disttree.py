@@ -52,13 +52,36 @@ def _declare(lib):
     lib.nbe_dist_export.argtypes = [vp, vp, C.POINTER(C.c_int), dp, C.POINTER(C.c_int), C.POINTER(C.c_int32), u64p]
     lib.nbe_dist_assemble.argtypes = [vp, C.POINTER(C.c_int32), u64p]
     lib.nbe_dist_advance.argtypes = [vp]
+    lib.nbe_dist_layout.argtypes = [vp, C.c_int, C.POINTER(C.c_int32), vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int32),
+                                    C.POINTER(C.c_int64)]
     lib.nbe_dist_download.argtypes = [vp, u64p, dp, dp, dp, C.POINTER(C.c_size_t)]
     for name in DIST_EXPORTS:
         getattr(lib, name).restype = C.c_int
     _declared = True
 
 
-DIST_EXPORTS = ["nbe_dist_upload", "nbe_dist_sample_keys", "nbe_dist_set_splitters", "nbe_dist_buffers", "nbe_dist_classify",
+TOP_CELL = np.dtype([("dst", "<i4"), ("skip", "<i4"), ("level", "<i4"), ("reserved", "<i4"), ("sum", "<f8", (4,))])
+
+
+def layout(all_frags, sizes):
+    """nbe_dist_layout: (spanning cells, first index of every fragment, total nodes) of the global pre-order made of the
+    given fragments (key order) with the given node counts.  Host only."""
+    lib = load_library()
+    _declare(lib)
+    all_frags = np.ascontiguousarray(all_frags, dtype=FRAGMENT)
+    sizes = np.ascontiguousarray(sizes, dtype=np.int32)
+    n = len(all_frags)
+    tops = np.zeros(max(n, 1), dtype=TOP_CELL)
+    dst = np.zeros(max(n, 1), dtype=np.int32)
+    nt, total = C.c_int(0), C.c_int64(0)
+    rc = lib.nbe_dist_layout(all_frags.ctypes.data, n, sizes.ctypes.data_as(C.POINTER(C.c_int32)), tops.ctypes.data, len(tops),
+                             C.byref(nt), dst.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(total))
+    if rc != 0:
+        raise EngineError(f"nbody_engine error {rc}: {lib.nbe_last_error().decode()}")
+    return tops[:nt.value].copy(), dst[:n].copy(), total.value
+
+
+DIST_EXPORTS = ["nbe_dist_layout", "nbe_dist_upload", "nbe_dist_sample_keys", "nbe_dist_set_splitters", "nbe_dist_buffers", "nbe_dist_classify",
                 "nbe_dist_receive", "nbe_dist_build", "nbe_dist_export", "nbe_dist_assemble", "nbe_dist_advance",
                 "nbe_dist_download"]
 
