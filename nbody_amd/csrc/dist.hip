@@ -40,7 +40,7 @@ struct TopCell {          // a cell that spans ranks
     double sum[4];
 };
 
-#define BOX_PARTS 64      // workgroups that share the bodies of one box
+#define BOX_PARTS 32      // workgroups that share the bodies of one fragment
 #define EXPORT_BATCH 8    // destinations whose exports are made by the same launches
 
 struct DistState {
@@ -61,17 +61,17 @@ struct DistState {
     int* d_nfrag = nullptr;             // [0] count, [1] overflow flag of the export buffer
     nbe_fragment_t* h_frags = nullptr;  // pinned
     int* h_small = nullptr;             // pinned scratch: counters and sizes
-    double* d_aabb = nullptr;           // [MAX_BOXES][6] boxes, then [MAX_BOXES][BOX_PARTS][6] partial ones
-    double* h_aabb = nullptr;           // pinned [MAX_BOXES][6]
-    uint64_t* d_groups = nullptr;       // [MAX_BOXES][2] first and last key of the runs of fragments that share a box
+    double* d_aabb = nullptr;           // [MAX_FRAGMENTS][6] boxes of the fragments' bodies, then [MAX_FRAGMENTS][BOX_PARTS][6] partial ones
+    double* h_aabb = nullptr;           // pinned [MAX_FRAGMENTS][6]
     std::vector<nbe_fragment_t> my_frags;          // sorted by key
     std::vector<nbe_fragment_t> all_frags;         // rank after rank
     std::vector<int> frag_counts;
     // export
-    uint32_t* x_diff = nullptr;         // (2 cap + 2) per destination of a batch, + 1
+    uint32_t* x_diff = nullptr;         // export work arrays, see export_t
     uint32_t* x_cover = nullptr;
     uint32_t* x_flag = nullptr;
     uint32_t* x_index = nullptr;
+    int* d_seg_first = nullptr;         // per segment: its first work item (assemble_kernel)
     void* export_nodes = nullptr;
     size_t export_cap = 0;
     unsigned long long* d_export_base = nullptr;   // [0, world] first exported node per destination and the end; then two batch bases
@@ -101,8 +101,8 @@ void dist_destroy(nbe_engine* e)
     if (!d) return;
     void** dev[] = {(void**)&d->d_split, (void**)&d->d_counts, &d->outbox, &d->inbox, (void**)&d->free_slots, (void**)&d->d_frags,
                     (void**)&d->d_nfrag, (void**)&d->d_aabb, (void**)&d->x_diff, (void**)&d->x_cover, (void**)&d->x_flag,
-                    (void**)&d->x_index, &d->export_nodes, (void**)&d->d_export_base, (void**)&d->d_export_sizes,
-                    (void**)&d->d_boxes, (void**)&d->d_box_counts, (void**)&d->d_groups, &d->import_nodes, &d->let_nodes, (void**)&d->let_counters, (void**)&d->d_segments,
+                    (void**)&d->x_index, (void**)&d->d_seg_first, &d->export_nodes, (void**)&d->d_export_base, (void**)&d->d_export_sizes,
+                    (void**)&d->d_boxes, (void**)&d->d_box_counts, &d->import_nodes, &d->let_nodes, (void**)&d->let_counters, (void**)&d->d_segments,
                     (void**)&d->d_top};
     for (void** p : dev) (void)dfree(p);
     void* host[] = {d->h_counts, d->h_frags, d->h_small, d->h_aabb};
@@ -189,14 +189,14 @@ extern "C" int nbe_dist_upload(nbe_engine* e, int rank, int world, size_t capaci
     NBE_HIP(hipMalloc((void**)&d->d_nfrag, 2 * sizeof(int)));
     NBE_HIP(hipHostMalloc((void**)&d->h_frags, NBE_DIST_MAX_FRAGMENTS * sizeof(nbe_fragment_t), hipHostMallocDefault));
     NBE_HIP(hipHostMalloc((void**)&d->h_small, (16 + (W2 + 1) * 2 + W2 * NBE_DIST_MAX_FRAGMENTS) * sizeof(int), hipHostMallocDefault));
-    NBE_HIP(hipMalloc((void**)&d->d_aabb, (size_t)NBE_DIST_MAX_BOXES * (BOX_PARTS + 1) * 6 * sizeof(double)));
-    NBE_HIP(hipHostMalloc((void**)&d->h_aabb, NBE_DIST_MAX_BOXES * 6 * sizeof(double), hipHostMallocDefault));
-    NBE_HIP(hipMalloc((void**)&d->d_groups, NBE_DIST_MAX_BOXES * 2 * sizeof(uint64_t)));
-    const size_t xlen = nodes2 * (W2 > EXPORT_BATCH ? (size_t)EXPORT_BATCH : (W2 > 1 ? W2 - 1 : 1)) + 1;
-    NBE_HIP(hipMalloc((void**)&d->x_diff, xlen * 4));
-    NBE_HIP(hipMalloc((void**)&d->x_cover, xlen * 4));
-    NBE_HIP(hipMalloc((void**)&d->x_flag, xlen * 4));
-    NBE_HIP(hipMalloc((void**)&d->x_index, xlen * 4));
+    NBE_HIP(hipMalloc((void**)&d->d_aabb, (size_t)NBE_DIST_MAX_FRAGMENTS * (BOX_PARTS + 1) * 6 * sizeof(double)));
+    NBE_HIP(hipHostMalloc((void**)&d->h_aabb, (size_t)NBE_DIST_MAX_FRAGMENTS * 6 * sizeof(double), hipHostMallocDefault));
+    // export work arrays (see export_t): two packed words per node and their scan, a byte and a 64-bit word per node,
+    // and the per-block counts of eight destinations with their scan
+    NBE_HIP(hipMalloc((void**)&d->x_diff, 2 * nodes2 * 4));
+    NBE_HIP(hipMalloc((void**)&d->x_cover, 2 * nodes2 * 4));
+    NBE_HIP(hipMalloc((void**)&d->x_flag, (nodes2 / 4 + 2 * ((size_t)EXPORT_BATCH * (nodes2 / 256 + 1) + 2) + 8) * 4));
+    NBE_HIP(hipMalloc((void**)&d->x_index, nodes2 * 8));
     // With few bodies per rank every other rank needs most of a rank's tree; with many, a small part of it.
     const size_t others = W2 > 5 ? 4 : (W2 > 1 ? W2 - 1 : 1);
     d->export_cap = nodes2 * others;
@@ -216,6 +216,7 @@ extern "C" int nbe_dist_upload(nbe_engine* e, int rank, int world, size_t capaci
     d->seg_cap = W2 * NBE_DIST_MAX_FRAGMENTS;
     d->top_cap = W2 * NBE_DIST_MAX_FRAGMENTS;
     NBE_HIP(hipMalloc((void**)&d->d_segments, d->seg_cap * sizeof(Segment)));
+    NBE_HIP(hipMalloc((void**)&d->d_seg_first, d->seg_cap * sizeof(int)));
     NBE_HIP(hipMalloc((void**)&d->d_top, d->top_cap * sizeof(TopCell)));
     d->split.assign(W2 + 1, 0);
     d->split[W2] = 1ull << 63;
@@ -384,7 +385,8 @@ static int classify_t(nbe_engine* e, uint32_t* send_counts)
                            e->orig[e->orig_cur], slots, lo[0], lo[1], lo[2], width, d->d_split, W, d->rank, d->d_counts, (S4*)d->outbox,
                            d->free_slots);
         NBE_HIP(hipGetLastError());
-        NBE_HIP(hipStreamSynchronize(e->stream));     // the caller reads the outbox on streams of its own
+        // a caller that has not given the engine its own stream reads the outbox on streams the engine knows nothing of
+        if (e->stream == e->own_stream) NBE_HIP(hipStreamSynchronize(e->stream));
     }
     return NBE_OK;
 }
@@ -478,20 +480,28 @@ __global__ __launch_bounds__(256) void fragments_kernel(const CNode* __restrict_
     f.level = leaf ? 255 : (int)c.level;
     f.start = p;
     f.nodes = c.skip - p;
-    f.reserved = 0;
+    f.reserved = at;                                  // its place in this (unordered) list: where its box will be
     for (int k = 0; k < 4; k++) f.sum[k] = node_sum[4 * (size_t)p + k];
     frags[at] = f;
 }
 
-// Box of the bodies whose keys lie in [groups[2g], groups[2g+1]]: BOX_PARTS workgroups share the run, then one reduces.
+// Box of the bodies of every fragment (its keys are the keys of its cell): BOX_PARTS workgroups share a fragment's bodies,
+// then one thread per fragment and coordinate reduces.  The grid covers the largest possible number of fragments.
 template <typename R4>
 __global__ __launch_bounds__(256) void box_partial_kernel(const R4* __restrict__ pos, const uint64_t* __restrict__ keys,
-                                                          const int* __restrict__ counters, const uint64_t* __restrict__ groups,
-                                                          double* __restrict__ part)
+                                                          const int* __restrict__ counters, const nbe_fragment_t* __restrict__ frags,
+                                                          const int* __restrict__ nfrag, double* __restrict__ part)
 {
     const int na = counters[0];
     const int g = blockIdx.y;
-    const uint64_t kmin = groups[2 * g], kmax = groups[2 * g + 1];
+    if (g >= *nfrag || g >= NBE_DIST_MAX_FRAGMENTS) return;
+    const nbe_fragment_t f = frags[g];
+    uint64_t kmin = f.key, kmax = f.key;
+    if (f.level < 21) {
+        const uint64_t size = 1ull << (3 * (21 - f.level));
+        kmin = f.key & ~(size - 1ull);
+        kmax = kmin + (size - 1ull);
+    }
     int lo = 0, hi = na;                              // first body with key >= kmin
     while (lo < hi) { const int mid = (lo + hi) >> 1; if (keys[mid] < kmin) lo = mid + 1; else hi = mid; }
     const int first = lo;
@@ -518,10 +528,11 @@ __global__ __launch_bounds__(256) void box_partial_kernel(const R4* __restrict__
     if (threadIdx.x < 6) part[((size_t)g * BOX_PARTS + blockIdx.x) * 6 + threadIdx.x] = s[threadIdx.x][0];
 }
 
-__global__ __launch_bounds__(64) void box_final_kernel(const double* __restrict__ part, double* __restrict__ out)
+__global__ __launch_bounds__(256) void box_final_kernel(const double* __restrict__ part, const int* __restrict__ nfrag, double* __restrict__ out)
 {
-    const int g = blockIdx.x, c = threadIdx.x;
-    if (c >= 6) return;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int g = t / 6, c = t % 6;
+    if (g >= *nfrag || g >= NBE_DIST_MAX_FRAGMENTS) return;
     double v = c < 3 ? INFINITY : -INFINITY;
     for (int b = 0; b < BOX_PARTS; b++) {
         const double x = part[((size_t)g * BOX_PARTS + b) * 6 + c];
@@ -542,15 +553,16 @@ static int common_level(uint64_t a, uint64_t b)
 // The rank's key range is a union of cells that may lie far apart (a range that crosses the middle of the bound holds
 // the end of one octant and the start of the next), so one box around all its bodies can span the bound.  The fragments,
 // in key order, are merged into at most NBE_DIST_MAX_BOXES runs: always the two neighbours that share the deepest cell.
-static void group_fragments(const std::vector<nbe_fragment_t>& fr, std::vector<uint64_t>* groups)
+static void group_fragments(const std::vector<nbe_fragment_t>& fr, std::vector<int>* groups)
 {
-    struct Run { uint64_t kmin, kmax; };
+    struct Run { uint64_t kmin, kmax; int first, last; };
     std::vector<Run> runs;
-    for (const nbe_fragment_t& f : fr) {
-        if (f.level >= 21) { runs.push_back(Run{f.key, f.key}); continue; }
+    for (size_t i = 0; i < fr.size(); i++) {
+        const nbe_fragment_t& f = fr[i];
+        if (f.level >= 21) { runs.push_back(Run{f.key, f.key, (int)i, (int)i}); continue; }
         const uint64_t size = 1ull << (3 * (21 - f.level));
         const uint64_t cmin = f.key & ~(size - 1ull);
-        runs.push_back(Run{cmin, cmin + (size - 1ull)});
+        runs.push_back(Run{cmin, cmin + (size - 1ull), (int)i, (int)i});
     }
     while (runs.size() > (size_t)NBE_DIST_MAX_BOXES) {
         size_t best = 0;
@@ -560,10 +572,11 @@ static void group_fragments(const std::vector<nbe_fragment_t>& fr, std::vector<u
             if (l > best_level) { best_level = l; best = i; }
         }
         runs[best].kmax = runs[best + 1].kmax;
+        runs[best].last = runs[best + 1].last;
         runs.erase(runs.begin() + (long)best + 1);
     }
     groups->clear();
-    for (const Run& r : runs) { groups->push_back(r.kmin); groups->push_back(r.kmax); }
+    for (const Run& r : runs) { groups->push_back(r.first); groups->push_back(r.last); }      // ranges of fragments, inclusive
 }
 
 extern "C" int nbe_dist_build(nbe_engine* e, nbe_fragment_t* frags, int max, int* count, double* boxes, int* nboxes, uint64_t* n_live)
@@ -583,6 +596,16 @@ extern "C" int nbe_dist_build(nbe_engine* e, nbe_fragment_t* frags, int max, int
         NBE_TRY(collide_emit_geometry(e));
         hipLaunchKernelGGL(fragments_kernel, dim3(cdiv(2 * e->n, 256)), dim3(256), 0, e->stream, e->cw.cnodes, e->tw.counters,
                            e->tw.node_sum, d->split[d->rank], d->split[d->rank + 1], d->d_frags, d->d_nfrag);
+        double* part = d->d_aabb + (size_t)NBE_DIST_MAX_FRAGMENTS * 6;
+        if (e->cfg.precision == NBE_PREC_F64)
+            hipLaunchKernelGGL((box_partial_kernel<double4>), dim3(BOX_PARTS, NBE_DIST_MAX_FRAGMENTS), dim3(256), 0, e->stream,
+                               (const double4*)key_positions(e), e->tw.keys[0], e->tw.counters, d->d_frags, d->d_nfrag, part);
+        else
+            hipLaunchKernelGGL((box_partial_kernel<float4>), dim3(BOX_PARTS, NBE_DIST_MAX_FRAGMENTS), dim3(256), 0, e->stream,
+                               (const float4*)key_positions(e), e->tw.keys[0], e->tw.counters, d->d_frags, d->d_nfrag, part);
+        hipLaunchKernelGGL(box_final_kernel, dim3(cdiv((size_t)NBE_DIST_MAX_FRAGMENTS * 6, 256)), dim3(256), 0, e->stream, part, d->d_nfrag,
+                           d->d_aabb);
+        NBE_HIP(hipMemcpyAsync(d->h_aabb, d->d_aabb, (size_t)NBE_DIST_MAX_FRAGMENTS * 6 * sizeof(double), hipMemcpyDeviceToHost, e->stream));
     }
     NBE_HIP(hipGetLastError());
     NBE_HIP(hipMemcpyAsync(d->h_small, e->tw.counters, 4 * sizeof(int), hipMemcpyDeviceToHost, e->stream));
@@ -595,24 +618,17 @@ extern "C" int nbe_dist_build(nbe_engine* e, nbe_fragment_t* frags, int max, int
     std::sort(d->my_frags.begin(), d->my_frags.end(), [](const nbe_fragment_t& a, const nbe_fragment_t& b) { return a.key < b.key; });
     if (nf) memcpy(frags, d->my_frags.data(), (size_t)nf * sizeof(nbe_fragment_t));
     *count = nf;
-    // the boxes of the rank's bodies, one per run of fragments
-    std::vector<uint64_t> groups;
+    // the boxes of the rank's bodies: one per run of fragments, the union of the fragments' boxes
+    std::vector<int> groups;
     group_fragments(d->my_frags, &groups);
     const int nb = (int)(groups.size() / 2);
-    if (nb > 0) {
-        NBE_HIP(hipMemcpyAsync(d->d_groups, groups.data(), groups.size() * sizeof(uint64_t), hipMemcpyHostToDevice, e->stream));
-        double* part = d->d_aabb + NBE_DIST_MAX_BOXES * 6;
-        if (e->cfg.precision == NBE_PREC_F64)
-            hipLaunchKernelGGL((box_partial_kernel<double4>), dim3(BOX_PARTS, nb), dim3(256), 0, e->stream, (const double4*)key_positions(e),
-                               e->tw.keys[0], e->tw.counters, d->d_groups, part);
-        else
-            hipLaunchKernelGGL((box_partial_kernel<float4>), dim3(BOX_PARTS, nb), dim3(256), 0, e->stream, (const float4*)key_positions(e),
-                               e->tw.keys[0], e->tw.counters, d->d_groups, part);
-        hipLaunchKernelGGL(box_final_kernel, dim3(nb), dim3(64), 0, e->stream, part, d->d_aabb);
-        NBE_HIP(hipGetLastError());
-        NBE_HIP(hipMemcpyAsync(d->h_aabb, d->d_aabb, (size_t)nb * 6 * sizeof(double), hipMemcpyDeviceToHost, e->stream));
-        NBE_HIP(hipStreamSynchronize(e->stream));
-        memcpy(boxes, d->h_aabb, (size_t)nb * 6 * sizeof(double));
+    for (int g = 0; g < nb; g++) {
+        double* bx = boxes + 6 * g;
+        for (int c = 0; c < 3; c++) { bx[c] = INFINITY; bx[3 + c] = -INFINITY; }
+        for (int i = groups[2 * (size_t)g]; i <= groups[2 * (size_t)g + 1]; i++) {
+            const double* fb = d->h_aabb + 6 * (size_t)d->my_frags[(size_t)i].reserved;
+            for (int c = 0; c < 3; c++) { bx[c] = fmin(bx[c], fb[c]); bx[3 + c] = fmax(bx[3 + c], fb[3 + c]); }
+        }
     }
     *nboxes = nb;
     if (n_live) *n_live = (uint64_t)na;
@@ -657,14 +673,14 @@ __device__ __forceinline__ bool may_open(const NodeD& nd, const double* __restri
     return false;
 }
 
-// The destinations are handled EXPORT_BATCH at a time: destination j of a batch owns elements [j*L, (j+1)*L) of the
-// work arrays (L = 2n + 2 >= nodes + 1), so one launch and one device-wide scan serve the whole batch.
+// The destinations are handled EXPORT_BATCH at a time, by the same launches (L = 2n + 2 >= nodes + 1 below).
 struct DestList { int q[EXPORT_BATCH]; int n; };
 
 // Cells inside the rank's key range that a destination's boxes cannot open hide everything below them: +1 on the node
-// after, -1 on the node after their subtree; the running sum is then the number of such cells above a node.  (The +1
-// and -1 of a cell fall into the same destination's stretch, so every stretch sums to zero and the running sum of the
-// concatenated array is that of each stretch.)
+// after, -1 on the node after their subtree; the running sum is then the number of such cells above a node (at most 21).
+// Four destinations share a 32-bit word, eight bits each: sums and differences are taken modulo 2^32, every true running
+// sum has all its fields in 0..21, so the scan of the packed words is exact whatever borrows its partial sums see.
+// diff[h * L + p]: word h (destinations 4h .. 4h+3) of node p.
 template <typename NodeT>
 __global__ __launch_bounds__(256) void export_mark_kernel(const NodeT* __restrict__ nodes, const CNode* __restrict__ cn,
                                                           const int* __restrict__ counters, uint64_t lo, uint64_t hi,
@@ -678,40 +694,76 @@ __global__ __launch_bounds__(256) void export_mark_kernel(const NodeT* __restric
     const CNode c = cn[p];
     if (c.body >= 0 || !cell_inside(c.key, c.level, lo, hi)) return;
     const NodeT nd = nodes[p];
+    uint32_t add[2] = {0u, 0u};
     for (int j = 0; j < dests.n; j++) {
         const int q = dests.q[j];
-        if (may_open(nd, boxes + 6 * (size_t)NBE_DIST_MAX_BOXES * q, nboxes[q], theta, eps2, slack, rel)) continue;
-        atomicAdd(&diff[j * L + p + 1], 1u);
-        atomicAdd(&diff[j * L + c.skip], 0xffffffffu);
+        if (!may_open(nd, boxes + 6 * (size_t)NBE_DIST_MAX_BOXES * q, nboxes[q], theta, eps2, slack, rel)) add[j >> 2] += 1u << (8 * (j & 3));
     }
+#pragma unroll
+    for (int h = 0; h < 2; h++)
+        if (add[h]) {
+            atomicAdd(&diff[h * L + p + 1], add[h]);
+            atomicAdd(&diff[h * L + c.skip], 0u - add[h]);
+        }
 }
 
-// cover = exclusive scan of diff: cover[j*L + p + 1] is the running sum up to and including node p.  A node goes to
-// destination j iff it belongs to a fragment (its cell is inside the key range) and nothing above it hides it.
-__global__ __launch_bounds__(256) void export_flag_kernel(const CNode* __restrict__ cn, const int* __restrict__ counters, uint64_t lo,
-                                                          uint64_t hi, const uint32_t* __restrict__ cover, size_t L, int ndest,
-                                                          uint32_t* __restrict__ flag)
+// cover = exclusive scan of diff (both words' stretches sum to zero, so one scan over 2L serves both): field j of
+// cover[.. + p + 1] is the number of closed cells above node p for destination j.  A node goes to destination j iff it
+// belongs to a fragment and that number is 0.  Per node: inc = the destinations it goes to (bit j), rank8 = for every
+// destination its rank among such nodes of its 256-node block (one byte each); per block and destination: the count.
+__global__ __launch_bounds__(256) void export_count_kernel(const CNode* __restrict__ cn, const int* __restrict__ counters, uint64_t lo,
+                                                           uint64_t hi, const uint32_t* __restrict__ cover, size_t L, int ndest,
+                                                           uint8_t* __restrict__ inc, unsigned long long* __restrict__ rank8,
+                                                           uint32_t* __restrict__ blockcnt, int nblk)
 {
     const int total = counters[1];
     const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
-    const int j = blockIdx.y;
-    if (p == 0 && j == 0) flag[(size_t)ndest * L] = 0;      // the scan's last element: the total of the batch
-    if (p >= L) return;
-    uint32_t v = 0;
+    unsigned mask = 0;
     if (p < (size_t)total) {
         const CNode c = cn[p];
-        const bool in = c.body >= 0 || cell_inside(c.key, c.level, lo, hi);
-        v = (in && cover[j * L + p + 1] == 0u) ? 1u : 0u;
+        if (c.body >= 0 || cell_inside(c.key, c.level, lo, hi)) {
+            const uint32_t c0 = cover[p + 1], c1 = cover[L + p + 1];
+            for (int j = 0; j < ndest; j++)
+                if ((((j < 4 ? c0 : c1) >> (8 * (j & 3))) & 0xffu) == 0u) mask |= 1u << j;
+        }
     }
-    flag[j * L + p] = v;
+    __shared__ uint32_t wcnt[EXPORT_BATCH][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned long long ranks = 0;
+#pragma unroll
+    for (int j = 0; j < EXPORT_BATCH; j++) {
+        const unsigned long long b = __builtin_amdgcn_ballot_w64((mask >> j) & 1u);
+        ranks |= (unsigned long long)__popcll(b & ((1ull << lane) - 1ull)) << (8 * j);
+        if (lane == 0) wcnt[j][wave] = (uint32_t)__popcll(b);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < EXPORT_BATCH; j++) {
+        uint32_t before = 0;
+        for (int w = 0; w < wave; w++) before += wcnt[j][w];
+        ranks += (unsigned long long)before << (8 * j);          // a rank is at most 255: no carry between the bytes
+    }
+    if (p < L) { inc[p] = (uint8_t)mask; rank8[p] = ranks; }
+    if (threadIdx.x < EXPORT_BATCH) {
+        const int j = threadIdx.x;
+        blockcnt[(size_t)j * nblk + blockIdx.x] = wcnt[j][0] + wcnt[j][1] + wcnt[j][2] + wcnt[j][3];
+        if (blockIdx.x == 0 && j == 0) blockcnt[(size_t)EXPORT_BATCH * nblk] = 0;      // the scan's last element: the batch's total
+    }
 }
 
-// index = exclusive scan of flag over the whole batch: index[j*L + p] counts the nodes exported before node p of
-// destination j, those of the batch's earlier destinations included, i.e. the node's place behind the batch's base.
+// blockoff = exclusive scan of blockcnt over all destinations of the batch: the place of node x in destination j's
+// export, counted from the batch's base, is blockoff[j][x / 256] + byte j of rank8[x].
+__device__ __forceinline__ uint32_t export_place(const uint32_t* __restrict__ blockoff, const unsigned long long* __restrict__ rank8,
+                                                 int nblk, int j, size_t x)
+{
+    return blockoff[(size_t)j * nblk + (x >> 8)] + (uint32_t)((rank8[x] >> (8 * j)) & 0xffull);
+}
+
 // Leaves the destinations' first nodes in base[q], the sizes of the fragments in there, and the next batch's base.
-__global__ __launch_bounds__(256) void export_sizes_kernel(const uint32_t* __restrict__ index, const nbe_fragment_t* __restrict__ frags,
-                                                           int nfrag, DestList dests, size_t L, unsigned long long* __restrict__ base,
-                                                           int world, const unsigned long long* __restrict__ batch_base,
+__global__ __launch_bounds__(256) void export_sizes_kernel(const uint32_t* __restrict__ blockoff, const unsigned long long* __restrict__ rank8,
+                                                           int nblk, const nbe_fragment_t* __restrict__ frags, int nfrag, DestList dests,
+                                                           unsigned long long* __restrict__ base, int world,
+                                                           const unsigned long long* __restrict__ batch_base,
                                                            unsigned long long* __restrict__ next_base, unsigned long long cap,
                                                            int* __restrict__ sizes, int* __restrict__ overflow)
 {
@@ -719,34 +771,43 @@ __global__ __launch_bounds__(256) void export_sizes_kernel(const uint32_t* __res
     const int j = blockIdx.y;
     const int q = dests.q[j];
     if (f == 0) {
-        base[q] = *batch_base + index[j * L];
+        base[q] = *batch_base + blockoff[(size_t)j * nblk];
         if (j == dests.n - 1) {
-            const unsigned long long end = *batch_base + index[(size_t)dests.n * L];
+            const unsigned long long end = *batch_base + blockoff[(size_t)EXPORT_BATCH * nblk];
             *next_base = end;
             base[world] = end;
             if (end > cap) *overflow = 1;
         }
     }
     if (f < nfrag)
-        sizes[(size_t)q * NBE_DIST_MAX_FRAGMENTS + f] =
-            (int)(index[j * L + frags[f].start + frags[f].nodes] - index[j * L + frags[f].start]);
+        sizes[(size_t)q * NBE_DIST_MAX_FRAGMENTS + f] = (int)(export_place(blockoff, rank8, nblk, j, (size_t)frags[f].start + frags[f].nodes) -
+                                                              export_place(blockoff, rank8, nblk, j, (size_t)frags[f].start));
 }
 
 template <typename NodeT>
 __global__ __launch_bounds__(256) void export_write_kernel(const NodeT* __restrict__ nodes, const int* __restrict__ counters,
-                                                           const uint32_t* __restrict__ flag, const uint32_t* __restrict__ index,
-                                                           size_t L, const unsigned long long* __restrict__ batch_base,
+                                                           const uint8_t* __restrict__ inc, const unsigned long long* __restrict__ rank8,
+                                                           const uint32_t* __restrict__ blockoff, int nblk, int ndest,
+                                                           const unsigned long long* __restrict__ batch_base,
                                                            const unsigned long long* __restrict__ next_base, unsigned long long cap,
                                                            NodeT* __restrict__ out)
 {
     const int total = counters[1];
     const int p = blockIdx.x * 256 + threadIdx.x;
-    const int j = blockIdx.y;
-    if (p >= total || !flag[j * L + p]) return;
-    if (*next_base > cap) return;                     // overflow: reported by the host, nothing written
+    if (p >= total) return;
+    const unsigned mask = inc[p];
+    if (!mask || *next_base > cap) return;            // (overflow: reported by the host, nothing written)
     NodeT nd = nodes[p];
-    nd.skip = (int)(index[j * L + nd.skip] - index[j * L]);      // relative to the first node of this destination's export
-    out[*batch_base + index[j * L + p]] = nd;
+    const int skip = nd.skip;
+    const unsigned long long mine = rank8[p], behind = rank8[skip];
+    for (int j = 0; j < ndest; j++) {
+        if (!((mask >> j) & 1u)) continue;
+        const uint32_t first = blockoff[(size_t)j * nblk];                      // the destination's first node
+        const uint32_t at = blockoff[(size_t)j * nblk + ((size_t)p >> 8)] + (uint32_t)((mine >> (8 * j)) & 0xffull);
+        const uint32_t to = blockoff[(size_t)j * nblk + ((size_t)skip >> 8)] + (uint32_t)((behind >> (8 * j)) & 0xffull);
+        nd.skip = (int)(to - first);                  // relative to the first node of this destination's export
+        out[*batch_base + at] = nd;
+    }
 }
 
 template <typename NodeT>
@@ -757,6 +818,7 @@ static int export_t(nbe_engine* e, int32_t* export_sizes, uint64_t* export_offse
     const int nf = (int)d->my_frags.size();
     const size_t n = e->n;
     const size_t L = 2 * n + 2;
+    const int nblk = (int)cdiv(L, 256);
     const uint64_t lo = d->split[d->rank], hi = d->split[d->rank + 1];
     const double eps2 = e->cfg.eps * e->cfg.eps;
     // rounding of a body's own distance: its coordinates and the node's are within the bound (|x| <= |centre| + width),
@@ -765,6 +827,13 @@ static int export_t(nbe_engine* e, int32_t* export_sizes, uint64_t* export_offse
     for (int c = 0; c < 3; c++) reach = fmax(reach, fabs(e->cfg.bound_center[c]) + e->cfg.bound_width);
     const double ulp = e->force64 ? 2.3e-16 : 1.2e-7;
     const double slack = 4.0 * ulp * reach, rel = 16.0 * ulp;
+    // work arrays, carved from the four buffers of (8 L + 1) words each
+    uint32_t* diff = d->x_diff;                                    // [2][L]
+    uint32_t* cover = d->x_cover;                                  // [2][L]
+    unsigned long long* rank8 = (unsigned long long*)d->x_index;   // [L]
+    uint8_t* inc = (uint8_t*)d->x_flag;                            // [L]
+    uint32_t* blockcnt = d->x_flag + (L + 3) / 4 + 1;              // [8][nblk] + 1
+    uint32_t* blockoff = blockcnt + (size_t)EXPORT_BATCH * nblk + 2;
     unsigned long long* batch_base = d->d_export_base + (W + 1);      // two device scalars used in turn
     NBE_HIP(hipMemsetAsync(d->d_export_base, 0, (size_t)(W + 3) * sizeof(unsigned long long), e->stream));
     NBE_HIP(hipMemsetAsync(d->d_nfrag + 1, 0, sizeof(int), e->stream));
@@ -778,21 +847,19 @@ static int export_t(nbe_engine* e, int32_t* export_sizes, uint64_t* export_offse
         DestList dl;
         dl.n = (int)std::min<size_t>(EXPORT_BATCH, others.size() - at);
         for (int j = 0; j < EXPORT_BATCH; j++) dl.q[j] = j < dl.n ? others[at + (size_t)j] : 0;
-        const size_t len = (size_t)dl.n * L;
         const unsigned long long* cur_base = batch_base + (batch & 1);
         unsigned long long* nxt_base = batch_base + ((batch + 1) & 1);
-        NBE_HIP(hipMemsetAsync(d->x_diff, 0, len * 4, e->stream));
+        NBE_HIP(hipMemsetAsync(diff, 0, 2 * L * 4, e->stream));
         hipLaunchKernelGGL((export_mark_kernel<NodeT>), dim3(cdiv(2 * n, 256)), dim3(256), 0, e->stream, (const NodeT*)e->tw.nodes,
-                           e->cw.cnodes, e->tw.counters, lo, hi, d->d_boxes, d->d_box_counts, dl, L, e->cfg.theta, eps2, slack, rel,
-                           d->x_diff);
-        NBE_TRY(device_scan_u32(e, d->x_diff, d->x_cover, len));
-        hipLaunchKernelGGL(export_flag_kernel, dim3(cdiv(L, 256), dl.n), dim3(256), 0, e->stream, e->cw.cnodes, e->tw.counters, lo, hi,
-                           d->x_cover, L, dl.n, d->x_flag);
-        NBE_TRY(device_scan_u32(e, d->x_flag, d->x_index, len + 1));
-        hipLaunchKernelGGL(export_sizes_kernel, dim3(cdiv(nf, 256), dl.n), dim3(256), 0, e->stream, d->x_index, d->d_frags, nf, dl, L,
+                           e->cw.cnodes, e->tw.counters, lo, hi, d->d_boxes, d->d_box_counts, dl, L, e->cfg.theta, eps2, slack, rel, diff);
+        NBE_TRY(device_scan_u32(e, diff, cover, 2 * L));
+        hipLaunchKernelGGL(export_count_kernel, dim3(nblk), dim3(256), 0, e->stream, e->cw.cnodes, e->tw.counters, lo, hi, cover, L, dl.n,
+                           inc, rank8, blockcnt, nblk);
+        NBE_TRY(device_scan_u32(e, blockcnt, blockoff, (size_t)EXPORT_BATCH * nblk + 1));
+        hipLaunchKernelGGL(export_sizes_kernel, dim3(cdiv(nf, 256), dl.n), dim3(256), 0, e->stream, blockoff, rank8, nblk, d->d_frags, nf, dl,
                            d->d_export_base, W, cur_base, nxt_base, (unsigned long long)d->export_cap, d->d_export_sizes, d->d_nfrag + 1);
-        hipLaunchKernelGGL((export_write_kernel<NodeT>), dim3(cdiv(2 * n, 256), dl.n), dim3(256), 0, e->stream, (const NodeT*)e->tw.nodes,
-                           e->tw.counters, d->x_flag, d->x_index, L, cur_base, nxt_base, (unsigned long long)d->export_cap,
+        hipLaunchKernelGGL((export_write_kernel<NodeT>), dim3(cdiv(2 * n, 256)), dim3(256), 0, e->stream, (const NodeT*)e->tw.nodes,
+                           e->tw.counters, inc, rank8, blockoff, nblk, dl.n, cur_base, nxt_base, (unsigned long long)d->export_cap,
                            (NodeT*)d->export_nodes);
         NBE_HIP(hipGetLastError());
     }
@@ -993,7 +1060,7 @@ extern "C" int nbe_dist_assemble(nbe_engine* e, const int32_t* import_sizes, con
     std::vector<int> seg_first(lay.segs.size());
     long long work = 0;
     for (size_t s = 0; s < lay.segs.size(); s++) { seg_first[s] = (int)work; work += lay.segs[s].count; }
-    int* d_seg_first = (int*)d->x_diff;               // free between export and the next one
+    int* d_seg_first = d->d_seg_first;
     if (!lay.segs.empty()) {
         NBE_HIP(hipMemcpyAsync(d->d_segments, lay.segs.data(), lay.segs.size() * sizeof(Segment), hipMemcpyHostToDevice, e->stream));
         NBE_HIP(hipMemcpyAsync(d_seg_first, seg_first.data(), seg_first.size() * sizeof(int), hipMemcpyHostToDevice, e->stream));

@@ -1025,7 +1025,7 @@ int tree_workspace_reserve(nbe_engine* e)
     const size_t nblocks = cdiv(cap, SORT_TILE);
     w.block_hist_len = 256 * nblocks;
     size_t scan_len = w.block_hist_len > cap + 1 ? w.block_hist_len : cap + 1;
-    if (e->dist && scan_len < 8 * (2 * cap + 2) + 1) scan_len = 8 * (2 * cap + 2) + 1;       // dist.hip scans over the nodes, for eight destinations at a time
+    if (e->dist && scan_len < 2 * (2 * cap + 2) + 1) scan_len = 2 * (2 * cap + 2) + 1;       // dist.hip scans two words per node
     w.scan_tmp_len = cdiv(scan_len, SCAN_TILE) + 1;
     if (w.scan_tmp_len < 256) w.scan_tmp_len = 256;      // also holds the 256 digit totals of a radix pass
     const size_t node_bytes = e->force64 ? sizeof(NodeD) : sizeof(NodeF);
