@@ -72,6 +72,10 @@ struct DistState {
     uint32_t* x_flag = nullptr;
     uint32_t* x_index = nullptr;
     int* d_seg_first = nullptr;         // per segment: its first work item (assemble_kernel)
+    Segment* h_segments = nullptr;      // pinned copies the layout is staged in, so that the upload needs no wait
+    int* h_seg_first = nullptr;
+    TopCell* h_top = nullptr;
+    int* h_let_counters = nullptr;
     void* export_nodes = nullptr;
     size_t export_cap = 0;
     unsigned long long* d_export_base = nullptr;   // [0, world] first exported node per destination and the end; then two batch bases
@@ -105,7 +109,7 @@ void dist_destroy(nbe_engine* e)
                     (void**)&d->d_boxes, (void**)&d->d_box_counts, &d->import_nodes, &d->let_nodes, (void**)&d->let_counters, (void**)&d->d_segments,
                     (void**)&d->d_top};
     for (void** p : dev) (void)dfree(p);
-    void* host[] = {d->h_counts, d->h_frags, d->h_small, d->h_aabb};
+    void* host[] = {d->h_counts, d->h_frags, d->h_small, d->h_aabb, d->h_segments, d->h_seg_first, d->h_top, d->h_let_counters};
     for (void* p : host)
         if (p) (void)hipHostFree(p);
     delete d;
@@ -217,6 +221,10 @@ extern "C" int nbe_dist_upload(nbe_engine* e, int rank, int world, size_t capaci
     d->top_cap = W2 * NBE_DIST_MAX_FRAGMENTS;
     NBE_HIP(hipMalloc((void**)&d->d_segments, d->seg_cap * sizeof(Segment)));
     NBE_HIP(hipMalloc((void**)&d->d_seg_first, d->seg_cap * sizeof(int)));
+    NBE_HIP(hipHostMalloc((void**)&d->h_segments, d->seg_cap * sizeof(Segment), hipHostMallocDefault));
+    NBE_HIP(hipHostMalloc((void**)&d->h_seg_first, d->seg_cap * sizeof(int), hipHostMallocDefault));
+    NBE_HIP(hipHostMalloc((void**)&d->h_top, d->top_cap * sizeof(TopCell), hipHostMallocDefault));
+    NBE_HIP(hipHostMalloc((void**)&d->h_let_counters, 2 * sizeof(int), hipHostMallocDefault));
     NBE_HIP(hipMalloc((void**)&d->d_top, d->top_cap * sizeof(TopCell)));
     d->split.assign(W2 + 1, 0);
     d->split[W2] = 1ull << 63;
@@ -1057,16 +1065,17 @@ extern "C" int nbe_dist_assemble(nbe_engine* e, const int32_t* import_sizes, con
     if ((size_t)lay.total > d->let_cap) { nbe_set_error("rank %d: the assembled tree (%d nodes) exceeds the buffer (%zu)", d->rank, lay.total, d->let_cap); return NBE_E_NOMEM; }
     if (lay.segs.size() > d->seg_cap || lay.tops.size() > d->top_cap) { nbe_set_error("too many fragments"); return NBE_E_UNSUPPORTED; }
     // work items: the nodes of all segments, numbered segment after segment
-    std::vector<int> seg_first(lay.segs.size());
+    // (the pinned staging copies of the previous step were consumed long ago: every step waits for the device several times)
     long long work = 0;
-    for (size_t s = 0; s < lay.segs.size(); s++) { seg_first[s] = (int)work; work += lay.segs[s].count; }
+    for (size_t s = 0; s < lay.segs.size(); s++) { d->h_seg_first[s] = (int)work; d->h_segments[s] = lay.segs[s]; work += lay.segs[s].count; }
+    for (size_t t = 0; t < lay.tops.size(); t++) d->h_top[t] = lay.tops[t];
     int* d_seg_first = d->d_seg_first;
     if (!lay.segs.empty()) {
-        NBE_HIP(hipMemcpyAsync(d->d_segments, lay.segs.data(), lay.segs.size() * sizeof(Segment), hipMemcpyHostToDevice, e->stream));
-        NBE_HIP(hipMemcpyAsync(d_seg_first, seg_first.data(), seg_first.size() * sizeof(int), hipMemcpyHostToDevice, e->stream));
+        NBE_HIP(hipMemcpyAsync(d->d_segments, d->h_segments, lay.segs.size() * sizeof(Segment), hipMemcpyHostToDevice, e->stream));
+        NBE_HIP(hipMemcpyAsync(d_seg_first, d->h_seg_first, lay.segs.size() * sizeof(int), hipMemcpyHostToDevice, e->stream));
     }
     if (!lay.tops.empty())
-        NBE_HIP(hipMemcpyAsync(d->d_top, lay.tops.data(), lay.tops.size() * sizeof(TopCell), hipMemcpyHostToDevice, e->stream));
+        NBE_HIP(hipMemcpyAsync(d->d_top, d->h_top, lay.tops.size() * sizeof(TopCell), hipMemcpyHostToDevice, e->stream));
     const double eps2 = e->cfg.eps * e->cfg.eps;
     const int ntops = (int)lay.tops.size();
     if (e->force64) {
@@ -1085,9 +1094,9 @@ extern "C" int nbe_dist_assemble(nbe_engine* e, const int32_t* import_sizes, con
                                (NodeF*)d->let_nodes);
     }
     NBE_HIP(hipGetLastError());
-    const int cnt[2] = {(int)d->live_hi, lay.total};
-    NBE_HIP(hipMemcpyAsync(d->let_counters, cnt, sizeof(cnt), hipMemcpyHostToDevice, e->stream));
-    NBE_HIP(hipStreamSynchronize(e->stream));         // the host vectors above go out of scope
+    d->h_let_counters[0] = (int)d->live_hi;
+    d->h_let_counters[1] = lay.total;
+    NBE_HIP(hipMemcpyAsync(d->let_counters, d->h_let_counters, 2 * sizeof(int), hipMemcpyHostToDevice, e->stream));
     d->assembled = true;
     e->stats.tree_nodes = (uint64_t)lay.total;
     return NBE_OK;
