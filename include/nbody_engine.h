@@ -289,6 +289,11 @@ int nbe_dist_layout(const nbe_fragment_t *all_frags, int nfrags, const int32_t *
                     int *ntops, int32_t *frag_dst, int64_t *total);
 /* Force pass over the assembled node array + fused update of the rank's bodies (main.go:130-149, 171-177). */
 int nbe_dist_advance(nbe_engine *e);
+/* This rank's share of nbe_energy, between nbe_dist_assemble and nbe_dist_advance (the state the next advance starts
+ * from): kinetic energy and momentum of its bodies, and its bodies' share of the potential energy, -G/2 sum m_i phi_i with
+ * phi_i summed over the nodes body i's walk accepts in the assembled array (all bodies of the run, softened by eps).  The
+ * run's totals are the sums over the ranks.  Synchronises. */
+int nbe_dist_energy(nbe_engine *e, double *kinetic, double *potential, double momentum[3]);
 /* The rank's live bodies: run-wide index, position, velocity, mass (any pointer may be NULL). */
 int nbe_dist_download(nbe_engine *e, uint64_t *index, double *pos_xyz, double *vel_xyz, double *mass, size_t *count);
 

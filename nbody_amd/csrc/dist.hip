@@ -1125,6 +1125,28 @@ extern "C" int nbe_dist_advance(nbe_engine* e)
     return NBE_OK;
 }
 
+extern "C" int nbe_dist_energy(nbe_engine* e, double* ke, double* pe, double mom[3])
+{
+    NBE_TRY(check_dist(e, "nbe_dist_energy"));
+    DistState* d = e->dist;
+    if (!d->assembled) { nbe_set_error("nbe_dist_energy needs the assembled tree (between nbe_dist_assemble and nbe_dist_advance)"); return NBE_E_INVALID; }
+    // instrumented walk: leaves every body's potential in the fourth component of its acceleration record
+    void* nodes = e->tw.nodes;
+    int* counters = e->tw.counters;
+    e->tw.nodes = d->let_nodes;
+    e->tw.counters = d->let_counters;
+    const int rc = tree_forces(e, e->cur, 0, e->n, false, true, e->cur ^ 1);
+    e->tw.nodes = nodes;
+    e->tw.counters = counters;
+    NBE_TRY(rc);
+    double h[5] = {0, 0, 0, 0, 0};
+    NBE_TRY(energy_local_sums(e, (int)d->live_hi, true, h));
+    if (ke) *ke = h[0];
+    if (mom) { mom[0] = h[1]; mom[1] = h[2]; mom[2] = h[3]; }
+    if (pe) *pe = -0.5 * e->cfg.G * h[4];
+    return NBE_OK;
+}
+
 extern "C" int nbe_dist_download(nbe_engine* e, uint64_t* index, double* pos, double* vel, double* mass, size_t* count)
 {
     NBE_TRY(check_dist(e, "nbe_dist_download"));

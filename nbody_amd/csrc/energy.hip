@@ -107,6 +107,13 @@ static int energy_t(nbe_engine* e, int n_live, bool tree_potential, double* host
     return NBE_OK;
 }
 
+// h[0] = kinetic energy, h[1..3] = momentum, h[4] = sum m_i phi_i of the first n_live bodies of the current state, phi
+// from e->acc (tree_potential) or from the fp64 pair sum over those bodies.
+int energy_local_sums(nbe_engine* e, int n_live, bool tree_potential, double h[5])
+{
+    return e->state64 ? energy_t<double4>(e, n_live, tree_potential, h) : energy_t<float4>(e, n_live, tree_potential, h);
+}
+
 int energy_compute(nbe_engine* e, double* ke, double* pe, double mom[3])
 {
     const bool tree_potential = e->cfg.mode == NBE_MODE_TREE && e->n > ENERGY_PAIR_SUM_MAX;

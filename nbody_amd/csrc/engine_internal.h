@@ -231,6 +231,7 @@ int direct_collide_free(nbe_engine* e);
 int direct_collide_step(nbe_engine* e, bool* replayed);
 // energy.hip
 int energy_compute(nbe_engine* e, double* ke, double* pe, double mom[3]);
+int energy_local_sums(nbe_engine* e, int n_live, bool tree_potential, double h[5]);
 // frames.hip
 int frame_stream_before_step(nbe_engine* e);    // called at the top of every step
 int frame_stream_guard_write(nbe_engine* e, int buf);

@@ -52,6 +52,7 @@ def _declare(lib):
     lib.nbe_dist_export.argtypes = [vp, vp, C.POINTER(C.c_int), dp, C.POINTER(C.c_int), C.POINTER(C.c_int32), u64p]
     lib.nbe_dist_assemble.argtypes = [vp, C.POINTER(C.c_int32), u64p]
     lib.nbe_dist_advance.argtypes = [vp]
+    lib.nbe_dist_energy.argtypes = [vp, dp, dp, dp]
     lib.nbe_dist_layout.argtypes = [vp, C.c_int, C.POINTER(C.c_int32), vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int32),
                                     C.POINTER(C.c_int64)]
     lib.nbe_dist_download.argtypes = [vp, u64p, dp, dp, dp, C.POINTER(C.c_size_t)]
@@ -81,7 +82,7 @@ def layout(all_frags, sizes):
     return tops[:nt.value].copy(), dst[:n].copy(), total.value
 
 
-DIST_EXPORTS = ["nbe_dist_layout", "nbe_dist_upload", "nbe_dist_sample_keys", "nbe_dist_set_splitters", "nbe_dist_buffers", "nbe_dist_classify",
+DIST_EXPORTS = ["nbe_dist_layout", "nbe_dist_energy", "nbe_dist_upload", "nbe_dist_sample_keys", "nbe_dist_set_splitters", "nbe_dist_buffers", "nbe_dist_classify",
                 "nbe_dist_receive", "nbe_dist_build", "nbe_dist_export", "nbe_dist_assemble", "nbe_dist_advance",
                 "nbe_dist_download"]
 
@@ -197,6 +198,13 @@ class DistRank:
 
     def advance(self):
         self._check(self._lib.nbe_dist_advance(self._h))
+
+    def energy(self):
+        """(kinetic, potential share, momentum[3]) of this rank's bodies; needs the assembled tree."""
+        ke, pe = C.c_double(), C.c_double()
+        mom = np.zeros(3)
+        self._check(self._lib.nbe_dist_energy(self._h, C.byref(ke), C.byref(pe), _dp(mom)))
+        return ke.value, pe.value, mom
 
     def download(self):
         n = self.capacity
@@ -315,10 +323,18 @@ def choose_splitters(samples, lives, world):
 class DistributedTree:
     """Steps the ranks that live in this process (all of them with LocalComm, one with TorchComm)."""
 
-    def __init__(self, ranks, comm):
+    def __init__(self, ranks, comm, rebalance_at=1.10):
+        """rebalance_at: new splitters are chosen before a step when the fullest rank holds this many times the mean
+        number of bodies (the bodies' distribution over key space drifts as the system evolves), or when a rank has filled
+        nine tenths of its slots; None = never."""
         self.ranks, self.comm = list(ranks), comm
         self.world = comm.world
         self.timings = None
+        self.rebalance_at = rebalance_at
+        self.rebalances = 0
+        self._prepared = False
+        self._want_rebalance = False
+        self.lives = None
 
     def distribute(self, max_samples=4096):
         """Chooses the splitters from samples of every rank's keys; the first step then moves every body to its owner."""
@@ -334,6 +350,15 @@ class DistributedTree:
     def step(self, nsteps=1):
         for _ in range(nsteps):
             self._step()
+
+    def energy(self):
+        """(kinetic, potential, momentum[3]) of the whole run for the current state (tree potential, softened by eps):
+        the sums of the ranks' shares, the same on every rank."""
+        if not self._prepared:
+            self._prepare()
+        mine = [np.array([ke, pe, *mom]) for ke, pe, mom in (r.energy() for r in self.ranks)]
+        tot = np.sum(self.comm.allgather(mine)[0], axis=0)
+        return float(tot[0]), float(tot[1]), tot[2:5].copy()
 
     def step_profiled(self):
         """One step with the device drained after every phase: returns the wall-clock milliseconds of each phase summed
@@ -357,7 +382,21 @@ class DistributedTree:
         self._t0 = now
 
     def _step(self):
+        if not self._prepared:
+            self._prepare()
+        for r in self.ranks:
+            r.advance()
+        self._prepared = False
+        self._mark("walk")
+
+    def _prepare(self):
+        """Everything of a step but the force pass: migration, local builds, exchange of pruned fragments, assembly."""
         R, W = self.ranks, self.world
+        if self._want_rebalance:
+            self.distribute()
+            self.rebalances += 1
+            self._want_rebalance = False
+            self._mark("rebalance")
         # bodies that crossed a splitter go to their new owner
         send = [r.classify() for r in R]
         self._mark("classify")
@@ -370,7 +409,14 @@ class DistributedTree:
         built = [r.build() for r in R]
         self._mark("sort_build")
         frags = self.comm.allgather([b[0] for b in built])
-        boxes = self.comm.allgather([b[1] for b in built])
+        # (the number of bodies rides with the boxes: every rank sees every rank's, and all take the same decision)
+        boxes = self.comm.allgather([np.concatenate([b[1].reshape(-1), [float(b[2]), float(r.capacity)]]) for b, r in zip(built, R)])
+        self.lives = [int(a[-2]) for a in boxes[0]]
+        fill = max(a[-2] / a[-1] for a in boxes[0])
+        boxes = [[a[:-2].reshape(-1, 6) for a in per_rank] for per_rank in boxes]
+        if self.rebalance_at is not None and sum(self.lives) > 0:
+            mean = sum(self.lives) / W
+            self._want_rebalance = max(self.lives) > self.rebalance_at * mean + 64 or fill > 0.9
         exported = []
         for k, r in enumerate(R):
             counts = np.array([len(f) for f in frags[k]], dtype=np.int32)
@@ -393,10 +439,8 @@ class DistributedTree:
                 imp.append(m[r.rank])
             offs = np.concatenate([[0], np.cumsum(recvn[k])[:-1]]).astype(np.uint64)
             r.assemble(np.concatenate(imp) if len(imp) else np.zeros(0, np.int32), offs)
+        self._prepared = True
         self._mark("exchange_assemble")
-        for r in R:
-            r.advance()
-        self._mark("walk")
 
     def download(self):
         """(index, pos, vel, mass) of the bodies of the ranks in this process, sorted by run-wide index."""

@@ -13,7 +13,7 @@ from oracle import oracle as O
 pytestmark = pytest.mark.gpu
 
 
-def run_distributed(b, world, nsteps, capacity=None, per_step=None, **kw):
+def run_distributed(b, world, nsteps, capacity=None, per_step=None, rebalance_at=1.10, **kw):
     n = len(b)
     per = (n + world - 1) // world
     ranks = [DistRank(r, world, **kw) for r in range(world)]
@@ -22,7 +22,7 @@ def run_distributed(b, world, nsteps, capacity=None, per_step=None, **kw):
             a, z = min(n, r.rank * per), min(n, (r.rank + 1) * per)
             r.upload(capacity or int(per * 1.5) + 1024, b.pos[a:z], b.vel[a:z], b.mass[a:z], a)
             r.use_torch_stream()
-        dt = DistributedTree(ranks, LocalComm(world))
+        dt = DistributedTree(ranks, LocalComm(world), rebalance_at=rebalance_at)
         dt.distribute()
         for s in range(nsteps):
             dt.step(1)
@@ -170,3 +170,49 @@ def test_one_process_per_rank_over_torch_distributed(gpu, tmp_path, world, preci
     assert all(len(r["ids"]) > 0 for r in res)
     for name, w in (("pos", want[1]), ("vel", want[2]), ("mass", want[3])):
         assert np.array_equal(np.concatenate([r[name] for r in res])[order], w), name
+
+
+def test_new_splitters_during_a_run_change_nothing_but_the_owners(gpu):
+    """Splitters are chosen anew whenever a rank holds too many bodies (forced here before every step): bodies change
+    owner wholesale, the trajectories stay those of one engine."""
+    b = physics.plummer(20000, seed=6, a=2e3)
+    seen = []
+    got = run_distributed(b, 4, 5, precision="f32", theta=0.6, rebalance_at=0.0,
+                          per_step=lambda s, dt: seen.append((dt.rebalances, list(dt.lives))))
+    want = run_one(b, 5, precision="f32", theta=0.6)
+    assert seen[-1][0] == 4 and all(sum(l) == 20000 for _, l in seen)
+    assert np.array_equal(got[0], want[0])
+    for a, w in zip(got[1:], want[1:]):
+        assert np.array_equal(a, w)
+
+
+def test_energy_of_a_distributed_run(gpu):
+    """The ranks' shares of the kinetic energy, the momentum and the tree potential add up to what one engine reports for
+    the same state (above 262,144 bodies one engine also sums the potential over the nodes its walk accepts)."""
+    n, world = 300000, 4
+    b = physics.plummer(n, seed=9, a=2e3)
+    per = (n + world - 1) // world
+    ranks = [DistRank(r, world, precision="f32", theta=0.5, eps=1.0) for r in range(world)]
+    try:
+        for r in ranks:
+            a, z = r.rank * per, min(n, (r.rank + 1) * per)
+            r.upload(int(per * 1.5), b.pos[a:z], b.vel[a:z], b.mass[a:z], a)
+            r.use_torch_stream()
+        dt = DistributedTree(ranks, LocalComm(world))
+        dt.distribute()
+        dt.step(2)
+        ke, pe, mom = dt.energy()
+        dt.step(1)                                     # the prepared state is used, not rebuilt
+        got = dt.download()
+    finally:
+        for r in ranks:
+            r.close()
+    with Engine(mode="tree", precision="f32", theta=0.5, eps=1.0, tree_sums=True) as e:
+        e.upload(b.pos, b.vel, b.mass)
+        e.step(2)
+        ke1, pe1, mom1 = e.energy()
+        e.step(1)
+        p, v, m, ids = e.download()
+    assert abs(ke - ke1) <= 1e-12 * ke1 and abs(pe - pe1) <= 1e-10 * abs(pe1)
+    assert np.abs(mom - mom1).max() <= 1e-12 * (b.mass * np.linalg.norm(b.vel, axis=1)).sum()
+    assert np.array_equal(got[0], ids) and np.array_equal(got[1], p) and np.array_equal(got[2], v)
