@@ -61,6 +61,27 @@ with open(os.path.join(root, "profiles", f"{tag}_kernel_stats.txt"), "w") as f:
             f.write(f"{k:28s} {a[0]:7d} {a[1]:14.1f} {a[1] / a[0]:12.2f} {a[2]:12.2f} {a[3]:12.2f} {100 * a[1] / total:6.2f}%\n")
         f.write("\n")
 
+# ---- the distributed tree: eight ranks side by side on one GPU ----
+agg = defaultdict(lambda: [0, 0.0, 1e30, 0.0])
+for r in rows("trace_dist/**/*kernel_trace.csv"):
+    d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+    name = r["Kernel_Name"].split("(")[0].replace("void ", "")
+    name = name.split("<")[0]
+    a = agg[name]
+    a[0] += 1; a[1] += d; a[2] = min(a[2], d); a[3] = max(a[3], d)
+if agg:
+    with open(os.path.join(root, "profiles", f"{tag}_dist_kernel_stats.txt"), "w") as f:
+        total = sum(a[1] for a in agg.values())
+        f.write(f"# rocprofv3 --kernel-trace --stats -- python3 profiles/dist_step.py   (tag {tag})\n"
+                f"# key-range-distributed tree, 16,777,216 bodies, eight ranks on one GPU, 8 steps (the first moves every body\n"
+                f"# to its owner: classify_kernel and pack_kernel are dominated by it); per rank and step divide calls by 64\n")
+        f.write(f"{'kernel':32s} {'calls':>7s} {'total_us':>14s} {'avg_us':>12s} {'min_us':>12s} {'max_us':>12s} {'share':>7s}\n")
+        for k, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+            f.write(f"{k:32s} {a[0]:7d} {a[1]:14.1f} {a[1] / a[0]:12.2f} {a[2]:12.2f} {a[3]:12.2f} {100 * a[1] / total:6.2f}%\n")
+        log = os.path.join(base, "dist_step.log")
+        if os.path.exists(log):
+            f.write("\n# " + "# ".join(l for l in open(log) if l.startswith("phase")))
+
 # ---- counters ----
 pmc = defaultdict(lambda: defaultdict(lambda: [0, 0.0]))
 for sub in ("pmc_fetch_direct", "pmc_write_direct", "pmc_fetch_tree", "pmc_write_tree", "pmc_sq_direct", "pmc_sq_tree",

@@ -216,3 +216,65 @@ def test_energy_of_a_distributed_run(gpu):
     assert abs(ke - ke1) <= 1e-12 * ke1 and abs(pe - pe1) <= 1e-10 * abs(pe1)
     assert np.abs(mom - mom1).max() <= 1e-12 * (b.mass * np.linalg.norm(b.vel, axis=1)).sum()
     assert np.array_equal(got[0], ids) and np.array_equal(got[1], p) and np.array_equal(got[2], v)
+
+
+def test_long_run_of_colliding_galaxies_with_owners_changing(gpu):
+    """150 steps of two galaxies on approach on four ranks: thousands of bodies change owner, the splitters are chosen
+    anew whenever the fullest rank is 2 % over the mean, and the state still equals one engine's bit for bit; energy and
+    momentum of the distributed run stay within the drift of the integrator."""
+    b = physics.galaxy_pair(20000, seed=3)
+    moved, rebal = [], []
+    e0 = []
+
+    def watch(s, dt):
+        moved.append(sum(dt.last_migrated))
+        rebal.append(dt.rebalances)
+        if s in (0, 149):
+            e0.append(dt.energy())
+    got = run_distributed(b, 4, 150, precision="f32", theta=0.6, eps=1.0, rebalance_at=1.02, per_step=watch)
+    want = run_one(b, 150, precision="f32", theta=0.6, eps=1.0)
+    assert np.array_equal(got[0], want[0])
+    for a, w in zip(got[1:], want[1:]):
+        assert np.array_equal(a, w)
+    assert sum(moved[1:]) > 1000 and rebal[-1] >= 1
+    (ke0, pe0, p0), (ke1, pe1, p1) = e0
+    assert abs((ke1 + pe1) - (ke0 + pe0)) <= 2e-2 * abs(ke0 + pe0)
+    scale = (b.mass * np.linalg.norm(b.vel, axis=1)).sum()
+    assert np.abs(p1 - p0).max() <= 1e-3 * scale
+
+
+def test_one_rank_over_rccl(gpu):
+    """The collectives of TorchComm on the "nccl" backend (RCCL) with device buffers, on a one-rank group: the rank owns
+    every key, its one fragment is the whole tree, and the run equals one engine's."""
+    import os
+    import torch
+    import torch.distributed as dist
+    from nbody_amd.disttree import TorchComm
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29578")
+    created = not dist.is_initialized()
+    if created:
+        try:
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        except Exception as ex:                      # no rendezvous on this box: nothing to do with the engine
+            pytest.skip(f"cannot create a one-rank RCCL group here: {ex}")
+    try:
+        b = physics.plummer(30000, seed=4, a=2e3)
+        r = DistRank(0, 1, precision="f32", theta=0.6)
+        try:
+            r.upload(40000, b.pos, b.vel, b.mass, 0)
+            r.use_torch_stream()
+            comm = TorchComm()
+            assert comm.backend == "nccl"
+            dt = DistributedTree([r], comm)
+            dt.distribute()
+            dt.step(4)
+            got = dt.download()
+        finally:
+            r.close()
+        want = run_one(b, 4, precision="f32", theta=0.6)
+        for a, w in zip(got, want):
+            assert np.array_equal(a, w)
+    finally:
+        if created:
+            dist.destroy_process_group()
