@@ -40,8 +40,9 @@ struct TopCell {          // a cell that spans ranks
     double sum[4];
 };
 
-#define BOX_PARTS 32      // workgroups that share the bodies of one fragment
+#define BOX_PARTS 128     // workgroups that share the bodies of one fragment
 #define EXPORT_BATCH 8    // destinations whose exports are made by the same launches
+#define DIST_MAX_WORLD 1024   // ranks (per-destination counters of a workgroup live in LDS)
 
 struct DistState {
     int rank = 0, world = 1;
@@ -55,6 +56,7 @@ struct DistState {
     void* inbox = nullptr;
     uint32_t* free_slots = nullptr;     // slots vacated by the last classify
     uint32_t n_free = 0;
+    int frag_hint = 0;                  // fragments of the last build (sizes the grid of the next build's box kernel)
     bool classified = false, built = false, exported = false, assembled = false;
     // fragments of the last build
     nbe_fragment_t* d_frags = nullptr;
@@ -149,7 +151,7 @@ extern "C" int nbe_dist_upload(nbe_engine* e, int rank, int world, size_t capaci
         nbe_set_error("the distributed tree needs tree mode, collisions off, the per-body criterion and no reference_quirks");
         return NBE_E_UNSUPPORTED;
     }
-    if (world < 1 || world > 4096 || rank < 0 || rank >= world) { nbe_set_error("bad rank %d of %d", rank, world); return NBE_E_INVALID; }
+    if (world < 1 || world > DIST_MAX_WORLD || rank < 0 || rank >= world) { nbe_set_error("bad rank %d of %d", rank, world); return NBE_E_INVALID; }
     if (capacity < n || capacity == 0) { nbe_set_error("capacity %zu < n %zu (or 0)", capacity, n); return NBE_E_INVALID; }
     if (capacity > (1ull << 26) || first_index + n > 0xffffffffull) { nbe_set_error("at most 2^26 bodies per rank and 2^32 in all"); return NBE_E_UNSUPPORTED; }
     if (n > 0 && (!pos || !vel || !mass)) { nbe_set_error("nbe_dist_upload: NULL array"); return NBE_E_INVALID; }
@@ -317,17 +319,27 @@ __device__ __forceinline__ int owner_of(const uint64_t* __restrict__ split, int 
     return lo;
 }
 
+// Thousands of bodies leave a rank per step, for a handful of destinations: counted one by one in device memory they
+// queue up behind a few addresses (~10 ns each: 0.1 ms per step, 7 ms when every body moves).  A workgroup therefore
+// counts in LDS and adds its totals once.
 template <typename R4>
 __global__ __launch_bounds__(256) void classify_kernel(const R4* __restrict__ posk, int slots, double lox, double loy, double loz, double W,
-                                                       const uint64_t* __restrict__ split, int world, int rank, uint32_t* __restrict__ counts)
+                                                       const uint64_t* __restrict__ split, int world, uint64_t own_lo, uint64_t own_hi,
+                                                       uint32_t* __restrict__ counts)
 {
+    __shared__ uint32_t cnt[DIST_MAX_WORLD];
+    for (int t = threadIdx.x; t < world; t += 256) cnt[t] = 0;
+    __syncthreads();
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= slots) return;
-    const R4 p = posk[i];
-    const uint64_t key = body_key((double)p.x, (double)p.y, (double)p.z, lox, loy, loz, W);
-    if (key == KEY_DEAD) return;
-    const int dest = owner_of(split, world, key);
-    if (dest != rank) atomicAdd(&counts[dest], 1u);
+    if (i < slots) {
+        const R4 p = posk[i];
+        const uint64_t key = body_key((double)p.x, (double)p.y, (double)p.z, lox, loy, loz, W);
+        // (nearly every body stays: no search for those)
+        if (key != KEY_DEAD && !(key >= own_lo && key < own_hi)) atomicAdd(&cnt[owner_of(split, world, key)], 1u);
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < world; t += 256)
+        if (cnt[t]) atomicAdd(&counts[t], cnt[t]);
 }
 
 // A record is the body's position+mass element followed by its velocity element, whose unused fourth component carries
@@ -341,22 +353,36 @@ template <typename R4, typename S4>
 __global__ __launch_bounds__(256) void pack_kernel(const R4* __restrict__ posk, S4* __restrict__ posm, S4* __restrict__ vel,
                                                    float4* __restrict__ mirror, const uint32_t* __restrict__ orig, int slots, double lox,
                                                    double loy, double loz, double W, const uint64_t* __restrict__ split, int world,
-                                                   int rank, uint32_t* __restrict__ counts, S4* __restrict__ outbox,
-                                                   uint32_t* __restrict__ free_slots)
+                                                   uint64_t own_lo, uint64_t own_hi, uint32_t* __restrict__ counts,
+                                                   S4* __restrict__ outbox, uint32_t* __restrict__ free_slots)
 {
+    // places are handed out per workgroup: ranks within the workgroup in LDS, one reservation per destination in memory
+    __shared__ uint32_t cnt[DIST_MAX_WORLD + 1], base[DIST_MAX_WORLD + 1];      // [world]: all destinations together
+    for (int t = threadIdx.x; t <= world; t += 256) cnt[t] = 0;
+    __syncthreads();
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= slots) return;
-    const R4 pk = posk[i];
-    const uint64_t key = body_key((double)pk.x, (double)pk.y, (double)pk.z, lox, loy, loz, W);
-    if (key == KEY_DEAD) return;
-    const int dest = owner_of(split, world, key);
-    if (dest == rank) return;
-    const uint32_t at = atomicAdd(&counts[world + dest], 1u);
+    int dest = -1;
+    uint32_t mine = 0, mine_all = 0;
+    if (i < slots) {
+        const R4 pk = posk[i];
+        const uint64_t key = body_key((double)pk.x, (double)pk.y, (double)pk.z, lox, loy, loz, W);
+        if (key != KEY_DEAD && !(key >= own_lo && key < own_hi)) {
+            dest = owner_of(split, world, key);
+            mine = atomicAdd(&cnt[dest], 1u);
+            mine_all = atomicAdd(&cnt[world], 1u);
+        }
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t <= world; t += 256)
+        if (cnt[t]) base[t] = atomicAdd(&counts[t == world ? 2 * world : world + t], cnt[t]);
+    __syncthreads();
+    if (dest < 0) return;
+    const uint32_t at = base[dest] + mine;
     S4 p = posm[i], v = vel[i];
     put_index(v, orig[i]);
     outbox[2 * (size_t)at] = p;
     outbox[2 * (size_t)at + 1] = v;
-    free_slots[atomicAdd(&counts[2 * world], 1u)] = (uint32_t)i;
+    free_slots[base[world] + mine_all] = (uint32_t)i;
     // the slot now holds a massless body parked outside the bound
     p.x = lox + 2.0 * W; p.y = loy + 2.0 * W; p.z = loz + 2.0 * W; p.w = 0;
     v.x = 0; v.y = 0; v.z = 0; v.w = 0;
@@ -377,7 +403,7 @@ static int classify_t(nbe_engine* e, uint32_t* send_counts)
     NBE_HIP(hipMemsetAsync(d->d_counts, 0, (2 * (size_t)W + 1) * 4, e->stream));
     if (slots > 0) {
         hipLaunchKernelGGL((classify_kernel<R4>), dim3(cdiv(slots, 256)), dim3(256), 0, e->stream, posk, slots, lo[0], lo[1], lo[2], width,
-                           d->d_split, W, d->rank, d->d_counts);
+                           d->d_split, W, d->split[d->rank], d->split[d->rank + 1], d->d_counts);
         NBE_HIP(hipGetLastError());
     }
     NBE_HIP(hipMemcpyAsync(d->h_counts, d->d_counts, (size_t)W * 4, hipMemcpyDeviceToHost, e->stream));
@@ -390,8 +416,8 @@ static int classify_t(nbe_engine* e, uint32_t* send_counts)
         NBE_TRY(frame_stream_guard_write(e, e->cur));
         hipLaunchKernelGGL((pack_kernel<R4, S4>), dim3(cdiv(slots, 256)), dim3(256), 0, e->stream, posk, (S4*)e->posm[e->cur],
                            (S4*)e->vel[e->cur], e->cfg.precision == NBE_PREC_MIXED ? e->mirror[e->cur] : (float4*)nullptr,
-                           e->orig[e->orig_cur], slots, lo[0], lo[1], lo[2], width, d->d_split, W, d->rank, d->d_counts, (S4*)d->outbox,
-                           d->free_slots);
+                           e->orig[e->orig_cur], slots, lo[0], lo[1], lo[2], width, d->d_split, W, d->split[d->rank], d->split[d->rank + 1],
+                           d->d_counts, (S4*)d->outbox, d->free_slots);
         NBE_HIP(hipGetLastError());
         // a caller that has not given the engine its own stream reads the outbox on streams the engine knows nothing of
         if (e->stream == e->own_stream) NBE_HIP(hipStreamSynchronize(e->stream));
@@ -587,6 +613,23 @@ static void group_fragments(const std::vector<nbe_fragment_t>& fr, std::vector<i
     for (const Run& r : runs) { groups->push_back(r.first); groups->push_back(r.last); }      // ranges of fragments, inclusive
 }
 
+// Boxes of the first `rows` fragments of the device list, into d->h_aabb (queued; the caller waits).
+static int fragment_boxes(nbe_engine* e, int rows)
+{
+    DistState* d = e->dist;
+    double* part = d->d_aabb + (size_t)NBE_DIST_MAX_FRAGMENTS * 6;
+    if (e->cfg.precision == NBE_PREC_F64)
+        hipLaunchKernelGGL((box_partial_kernel<double4>), dim3(BOX_PARTS, rows), dim3(256), 0, e->stream, (const double4*)key_positions(e),
+                           e->tw.keys[0], e->tw.counters, d->d_frags, d->d_nfrag, part);
+    else
+        hipLaunchKernelGGL((box_partial_kernel<float4>), dim3(BOX_PARTS, rows), dim3(256), 0, e->stream, (const float4*)key_positions(e),
+                           e->tw.keys[0], e->tw.counters, d->d_frags, d->d_nfrag, part);
+    hipLaunchKernelGGL(box_final_kernel, dim3(cdiv((size_t)rows * 6, 256)), dim3(256), 0, e->stream, part, d->d_nfrag, d->d_aabb);
+    NBE_HIP(hipGetLastError());
+    NBE_HIP(hipMemcpyAsync(d->h_aabb, d->d_aabb, (size_t)rows * 6 * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    return NBE_OK;
+}
+
 extern "C" int nbe_dist_build(nbe_engine* e, nbe_fragment_t* frags, int max, int* count, double* boxes, int* nboxes, uint64_t* n_live)
 {
     NBE_TRY(check_dist(e, "nbe_dist_build"));
@@ -596,6 +639,9 @@ extern "C" int nbe_dist_build(nbe_engine* e, nbe_fragment_t* frags, int max, int
     // Only the slots that can hold bodies take part: the engine's body count is the number of those (its buffers keep
     // their capacity), so the sort, the build and the walk do not pay for the free slots behind them.
     e->n = d->live_hi;
+    // the box kernel's grid has a row per fragment; their number is known only after the read-back, so the grid is sized
+    // from the last build's (fragments come and go a few at a time) and the rare build that outgrows it runs it again
+    const int box_rows = std::min(NBE_DIST_MAX_FRAGMENTS, 2 * d->frag_hint + 64);
     NBE_HIP(hipMemsetAsync(d->d_nfrag, 0, 2 * sizeof(int), e->stream));
     if (e->n == 0) {
         NBE_HIP(hipMemsetAsync(e->tw.counters, 0, 16 * sizeof(int), e->stream));
@@ -604,16 +650,7 @@ extern "C" int nbe_dist_build(nbe_engine* e, nbe_fragment_t* frags, int max, int
         NBE_TRY(collide_emit_geometry(e));
         hipLaunchKernelGGL(fragments_kernel, dim3(cdiv(2 * e->n, 256)), dim3(256), 0, e->stream, e->cw.cnodes, e->tw.counters,
                            e->tw.node_sum, d->split[d->rank], d->split[d->rank + 1], d->d_frags, d->d_nfrag);
-        double* part = d->d_aabb + (size_t)NBE_DIST_MAX_FRAGMENTS * 6;
-        if (e->cfg.precision == NBE_PREC_F64)
-            hipLaunchKernelGGL((box_partial_kernel<double4>), dim3(BOX_PARTS, NBE_DIST_MAX_FRAGMENTS), dim3(256), 0, e->stream,
-                               (const double4*)key_positions(e), e->tw.keys[0], e->tw.counters, d->d_frags, d->d_nfrag, part);
-        else
-            hipLaunchKernelGGL((box_partial_kernel<float4>), dim3(BOX_PARTS, NBE_DIST_MAX_FRAGMENTS), dim3(256), 0, e->stream,
-                               (const float4*)key_positions(e), e->tw.keys[0], e->tw.counters, d->d_frags, d->d_nfrag, part);
-        hipLaunchKernelGGL(box_final_kernel, dim3(cdiv((size_t)NBE_DIST_MAX_FRAGMENTS * 6, 256)), dim3(256), 0, e->stream, part, d->d_nfrag,
-                           d->d_aabb);
-        NBE_HIP(hipMemcpyAsync(d->h_aabb, d->d_aabb, (size_t)NBE_DIST_MAX_FRAGMENTS * 6 * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+        NBE_TRY(fragment_boxes(e, box_rows));
     }
     NBE_HIP(hipGetLastError());
     NBE_HIP(hipMemcpyAsync(d->h_small, e->tw.counters, 4 * sizeof(int), hipMemcpyDeviceToHost, e->stream));
@@ -622,6 +659,11 @@ extern "C" int nbe_dist_build(nbe_engine* e, nbe_fragment_t* frags, int max, int
     NBE_HIP(hipStreamSynchronize(e->stream));
     const int na = d->h_small[0], nf = d->h_small[4];
     if (nf > NBE_DIST_MAX_FRAGMENTS || nf > max) { nbe_set_error("rank %d has %d fragments (limit %d)", d->rank, nf, std::min(max, NBE_DIST_MAX_FRAGMENTS)); return NBE_E_UNSUPPORTED; }
+    d->frag_hint = nf;
+    if (nf > box_rows) {
+        NBE_TRY(fragment_boxes(e, nf));
+        NBE_HIP(hipStreamSynchronize(e->stream));
+    }
     d->my_frags.assign(d->h_frags, d->h_frags + nf);
     std::sort(d->my_frags.begin(), d->my_frags.end(), [](const nbe_fragment_t& a, const nbe_fragment_t& b) { return a.key < b.key; });
     if (nf) memcpy(frags, d->my_frags.data(), (size_t)nf * sizeof(nbe_fragment_t));
@@ -657,27 +699,31 @@ extern "C" int nbe_dist_build(nbe_engine* e, nbe_fragment_t* frags, int max, int
 // measured from the cell's centre of mass.  The distance from that centre to the box bounds r from below; `slack` (absolute,
 // in metres) and `rel` cover the rounding of the body's own arithmetic, so a cell judged closed here is closed for every
 // body in the box whatever its roundings.
-__device__ __forceinline__ double box_distance(double x, double y, double z, const double* __restrict__ b)
+__device__ __forceinline__ double box_distance2(double x, double y, double z, const double* __restrict__ b)
 {
     const double dx = fmax(fmax(b[0] - x, x - b[3]), 0.0), dy = fmax(fmax(b[1] - y, y - b[4]), 0.0), dz = fmax(fmax(b[2] - z, z - b[5]), 0.0);
-    return sqrt(dx * dx + dy * dy + dz * dz);
+    return dx * dx + dy * dy + dz * dz;
 }
-__device__ __forceinline__ bool may_open(const NodeF& nd, const double* __restrict__ boxes, int nboxes, double theta, double eps2, double slack, double rel)
+// Square of the distance from the centre of mass within which a body may open the cell (0: never, a body's record).
+__device__ __forceinline__ double open_reach2(const NodeF& nd, double theta, double slack, double rel)
 {
-    if (!(nd.w2 > 0.0f)) return false;                // a body: never opened
-    for (int b = 0; b < nboxes; b++) {
-        const double dlow = fmax(box_distance((double)nd.x, (double)nd.y, (double)nd.z, boxes + 6 * b) - slack, 0.0);
-        if (dlow * dlow * (1.0 - rel) < (double)nd.w2 * (1.0 + rel)) return true;      // (eps^2 left out on the left: errs towards "may open")
-    }
-    return false;
+    if (!(nd.w2 > 0.0f)) return 0.0;
+    // opens iff r^2 < w2 (eps^2 on both sides with softening; left out on the left here: errs towards "may open")
+    const double t = sqrt((double)nd.w2 * (1.0 + rel) / (1.0 - rel)) + slack;
+    return t * t;
 }
-__device__ __forceinline__ bool may_open(const NodeD& nd, const double* __restrict__ boxes, int nboxes, double theta, double, double slack, double rel)
+__device__ __forceinline__ double open_reach2(const NodeD& nd, double theta, double slack, double rel)
 {
-    if (!(nd.w > 0.0)) return false;
-    for (int b = 0; b < nboxes; b++) {
-        const double dlow = fmax(box_distance(nd.x, nd.y, nd.z, boxes + 6 * b) - slack, 0.0);
-        if (nd.w * nd.w * (1.0 + rel) >= theta * theta * dlow * dlow * (1.0 - rel)) return true;
-    }
+    if (!(nd.w > 0.0)) return 0.0;
+    if (!(theta > 0.0)) return INFINITY;
+    const double t = nd.w * sqrt((1.0 + rel) / (1.0 - rel)) / theta + slack;      // opens iff w / r > theta
+    return t * t;
+}
+template <typename NodeT>
+__device__ __forceinline__ bool may_open(const NodeT& nd, double reach2, const double* __restrict__ boxes, int nboxes)
+{
+    for (int b = 0; b < nboxes; b++)
+        if (box_distance2((double)nd.x, (double)nd.y, (double)nd.z, boxes + 6 * b) < reach2) return true;
     return false;
 }
 
@@ -702,10 +748,11 @@ __global__ __launch_bounds__(256) void export_mark_kernel(const NodeT* __restric
     const CNode c = cn[p];
     if (c.body >= 0 || !cell_inside(c.key, c.level, lo, hi)) return;
     const NodeT nd = nodes[p];
+    const double reach2 = open_reach2(nd, theta, slack, rel);
     uint32_t add[2] = {0u, 0u};
     for (int j = 0; j < dests.n; j++) {
         const int q = dests.q[j];
-        if (!may_open(nd, boxes + 6 * (size_t)NBE_DIST_MAX_BOXES * q, nboxes[q], theta, eps2, slack, rel)) add[j >> 2] += 1u << (8 * (j & 3));
+        if (!may_open(nd, reach2, boxes + 6 * (size_t)NBE_DIST_MAX_BOXES * q, nboxes[q])) add[j >> 2] += 1u << (8 * (j & 3));
     }
 #pragma unroll
     for (int h = 0; h < 2; h++)
