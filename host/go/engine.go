@@ -35,6 +35,7 @@ type gpuOptions struct {
 	asGo      bool // tree mode: running cell centres (tree.go:189-193) and unwalked last n mod 4 bodies (main.go:134-148)
 	perWave   bool // tree mode: the bodies of a wavefront open cells together (faster, finer, not the reference's set)
 	gpus      int  // > 1: the engine drives GPUs 0 .. gpus-1 itself (body ranges fanned out as main.go:134-149 fans them over goroutines); with collisions on, tree mode only
+	distributed bool // with gpus > 1: the key-range-distributed tree (no GPU holds all bodies)
 }
 
 // gpuEngine owns one nbe_engine.  All calls happen on one locked OS thread, as the reference drives the step
@@ -74,6 +75,9 @@ func newGPUEngine(tree, nocollision bool, theta, dt float64, opt gpuOptions) *gp
 	}
 	if opt.gpus > 1 {
 		cfg.num_devices = C.int(opt.gpus) // device_ids stays nil: devices 0 .. gpus-1
+		if opt.distributed {
+			cfg.distributed = 1 // every body on one GPU only; needs -tree -nocollision; frames by blocking download
+		}
 	}
 	if tree && opt.asGo {
 		cfg.reference_quirks = C.int(C.NBE_QUIRK_REF_COM | C.NBE_QUIRK_DROP_TAIL)

@@ -243,7 +243,7 @@ int main(int argc, char** argv)
     int numbodies = 10;
     double years = 1;
     std::string stateFilename, framesDir = "frames";
-    bool stateSave = false, tree = false, norender = false, nocollision = false, asgo = false, perwave = false;
+    bool stateSave = false, tree = false, norender = false, nocollision = false, asgo = false, perwave = false, distributed = false;
     uint64_t seed = 1;
     double theta = 1;                                        // main.go:73
     double dt = 60 * 60;                                     // main.go:28
@@ -273,6 +273,7 @@ int main(int argc, char** argv)
         else if (const char* v = val("-precision")) precision = !std::strcmp(v, "f64") ? NBE_PREC_F64 : !std::strcmp(v, "mixed") ? NBE_PREC_MIXED : NBE_PREC_F32;
         else if (const char* v = val("-recode")) { exportFrameData(importFrameData(v)); return 0; }
         else if (a == "-save") stateSave = true;
+        else if (a == "-distributed") distributed = true;
         else if (a == "-tree") tree = true;
         else if (a == "-norender") norender = true;
         else if (a == "-nocollision") nocollision = true;
@@ -323,6 +324,9 @@ int main(int argc, char** argv)
     cfg.precision = precision;
     cfg.collisions = nocollision ? 0 : 1;                    // main.go:24
     cfg.num_devices = gpus;                                  // > 1: devices 0 .. gpus-1 (with collisions on: -tree only)
+    // -distributed (with -gpus N -tree -nocollision -norender): every body on one GPU only, pruned subtrees exchanged;
+    // frames are then taken with nbe_download instead of the frame stream
+    cfg.distributed = distributed ? 1 : 0;
     // -asgo: the tree path with the Go program's own arithmetic (running cell centres tree.go:189-193, last
     // n mod 4 bodies unwalked main.go:134-148), for comparing a run with the reference number for number
     if (asgo && tree) cfg.reference_quirks = NBE_QUIRK_REF_COM | NBE_QUIRK_DROP_TAIL;
@@ -352,6 +356,10 @@ int main(int argc, char** argv)
     ctx.ch = &ch;
     ctx.radius_by_id = &radius_by_id;
     ctx.remaining = (int)n;
+    if (distributed && !norender) {
+        std::fprintf(stderr, "-distributed keeps no GPU with all bodies, so there is no frame stream: run with -norender (and -save for the final state)\n");
+        return 2;
+    }
     if (!norender) check(nbe_frame_stream_begin(eng, iterPerFrame, 32, startFrame, on_frame, &ctx));
 
     const auto start = std::chrono::steady_clock::now();

@@ -55,6 +55,8 @@ typedef struct {
     int num_devices;        /* 0 or 1: one GPU, `device`.  G > 1: the engine drives G GPUs from this process, see below */
     int cell_sums;          /* tree mode, fp32 node records: NBE_SUMS_PREFIX (default) or NBE_SUMS_TREE, see below */
     const int *device_ids;  /* num_devices HIP device ordinals (copied by nbe_create); NULL = devices 0 .. G-1 */
+    int distributed;        /* with num_devices > 1 in tree mode: 1 = every body lives on one GPU only and the GPUs exchange
+                               pruned subtrees (the key-range-distributed tree, nbe_dist_* below, driven by the engine itself) */
 } nbe_config;
 
 /* Several GPUs behind one engine (num_devices = G > 1).  The reference's data-parallel strategy is a fan-out of
@@ -67,7 +69,12 @@ typedef struct {
  * nbe_stats, nbe_sync, nbe_tree_nodes, nbe_time_force_kernel and the frame stream work as with one GPU (reads come
  * from the first GPU; nbe_set_radius reaches every GPU).  Collisions work in tree mode (the GPUs share out the force pass and
  * each runs the search, the merges and the update of all bodies), not in the direct sum; nbe_step_timed, nbe_set_stream,
- * nbe_device_state and the nbe_shard_* calls are refused with NBE_E_UNSUPPORTED.  The same ordinal may be listed more than once (several shards on one GPU). */
+ * nbe_device_state and the nbe_shard_* calls are refused with NBE_E_UNSUPPORTED.  The same ordinal may be listed more than once (several shards on one GPU).
+ * With cfg.distributed = 1 (tree mode, collisions off, per-body criterion, no reference_quirks) the GPUs do not replicate the
+ * bodies: the engine runs the key-range-distributed tree described at nbe_dist_upload below on its GPUs, one host thread per
+ * GPU, with peer copies for the exchanges.  nbe_upload, nbe_step, nbe_download, nbe_stats, nbe_energy (tree potential) and
+ * nbe_sync work; results equal those of one GPU with cell_sums = NBE_SUMS_TREE bit for bit in fp32 and fp64; the other
+ * calls are refused. */
 
 /* How a cell's mass and centre of mass are summed (fp64 either way).
  *   NBE_SUMS_PREFIX   differences of prefix sums over the Morton-sorted bodies: three launches, the fastest, and the

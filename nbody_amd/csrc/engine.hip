@@ -49,6 +49,11 @@ static int use_device(nbe_engine* e)
         if ((e)->multi) { nbe_set_error(name " is not available on an engine with num_devices > 1"); return NBE_E_UNSUPPORTED; } \
     } while (0)
 #define NBE_FIRST(e) ((e) && (e)->multi ? multi_first(e) : (e))
+// ... and those that an engine with cfg.distributed cannot serve from one GPU
+#define NBE_NOT_DISTRIBUTED(e, name)                                                               \
+    do {                                                                                           \
+        if ((e) && multi_is_distributed(e)) { nbe_set_error(name " is not available on an engine with distributed = 1"); return NBE_E_UNSUPPORTED; } \
+    } while (0)
 
 static int free_state(nbe_engine* e)
 {
@@ -80,6 +85,8 @@ extern "C" int nbe_create(const nbe_config* cfg, nbe_engine** out)
     }
     if (cfg->reference_quirks && cfg->mode != NBE_MODE_TREE) { nbe_set_error("reference_quirks apply to tree mode only"); return NBE_E_INVALID; }
     if (cfg->num_devices < 0) { nbe_set_error("num_devices < 0"); return NBE_E_INVALID; }
+    if (cfg->distributed != 0 && cfg->distributed != 1) { nbe_set_error("distributed must be 0 or 1"); return NBE_E_INVALID; }
+    if (cfg->distributed && cfg->num_devices <= 1) { nbe_set_error("distributed = 1 needs num_devices > 1 (one GPU: use cell_sums = NBE_SUMS_TREE for the same results)"); return NBE_E_INVALID; }
     if (cfg->cell_sums != NBE_SUMS_PREFIX && cfg->cell_sums != NBE_SUMS_TREE) { nbe_set_error("bad cell_sums %d", cfg->cell_sums); return NBE_E_INVALID; }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
@@ -652,6 +659,7 @@ extern "C" int nbe_sync(nbe_engine* e)
 extern "C" int nbe_stats(nbe_engine* e, nbe_stats_t* stats)
 {
     if (!e || !stats) { nbe_set_error("NULL argument"); return NBE_E_INVALID; }
+    if (multi_is_distributed(e)) return multi_dist_stats(e, stats);
     e = NBE_FIRST(e);
     NBE_TRY(use_device(e));
     NBE_TRY(fetch_interactions(e));
@@ -698,6 +706,7 @@ static int accel_impl(nbe_engine* e, double* acc_xyz, uint8_t* alive_out)
 extern "C" int nbe_energy(nbe_engine* e, double* kinetic, double* potential, double momentum[3])
 {
     if (!e) { nbe_set_error("engine is NULL"); return NBE_E_INVALID; }
+    if (multi_is_distributed(e)) return multi_dist_energy(e, kinetic, potential, momentum);
     e = NBE_FIRST(e);
     NBE_TRY(use_device(e));
     if (e->advance_pending) { nbe_set_error("nbe_energy between nbe_shard_advance and nbe_shard_commit"); return NBE_E_INVALID; }
@@ -707,6 +716,7 @@ extern "C" int nbe_energy(nbe_engine* e, double* kinetic, double* potential, dou
 extern "C" int nbe_time_force_kernel(nbe_engine* e, int reps, float* ms_per_launch)
 {
     if (!e || !ms_per_launch || reps <= 0) { nbe_set_error("bad argument"); return NBE_E_INVALID; }
+    NBE_NOT_DISTRIBUTED(e, "nbe_time_force_kernel");
     e = NBE_FIRST(e);          // several GPUs: the first one's range
     NBE_TRY(use_device(e));
     if (e->advance_pending) { nbe_set_error("nbe_time_force_kernel inside a sharded step"); return NBE_E_INVALID; }
@@ -770,12 +780,28 @@ static int tree_nodes_impl(nbe_engine* e, double* out, size_t cap, size_t* count
     try { return (call); }                                                               \
     catch (const std::bad_alloc&) { nbe_set_error("out of host memory"); return NBE_E_NOMEM; }
 
-extern "C" int nbe_download(nbe_engine* e, double* pos, double* vel, double* mass, uint64_t* id, size_t* n_alive_out) { NBE_GUARDED(download_impl(NBE_FIRST(e), pos, vel, mass, id, n_alive_out)) }
+extern "C" int nbe_download(nbe_engine* e, double* pos, double* vel, double* mass, uint64_t* id, size_t* n_alive_out)
+{
+    if (e && multi_is_distributed(e)) { NBE_GUARDED(multi_dist_download(e, pos, vel, mass, id, n_alive_out)) }
+    NBE_GUARDED(download_impl(NBE_FIRST(e), pos, vel, mass, id, n_alive_out))
+}
 extern "C" int nbe_set_radius(nbe_engine* e, const double* radius)
 {
     if (e && e->multi) return multi_set_radius(e, radius);      // every GPU's engine holds the radii
     NBE_GUARDED(set_radius_impl(e, radius))
 }
-extern "C" int nbe_get_radius(nbe_engine* e, double* radius, size_t* n_alive_out) { NBE_GUARDED(get_radius_impl(NBE_FIRST(e), radius, n_alive_out)) }
-extern "C" int nbe_accel(nbe_engine* e, double* acc_xyz, uint8_t* alive_out) { NBE_GUARDED(accel_impl(NBE_FIRST(e), acc_xyz, alive_out)) }
-extern "C" int nbe_tree_nodes(nbe_engine* e, double* out, size_t cap, size_t* count) { NBE_GUARDED(tree_nodes_impl(NBE_FIRST(e), out, cap, count)) }
+extern "C" int nbe_get_radius(nbe_engine* e, double* radius, size_t* n_alive_out)
+{
+    NBE_NOT_DISTRIBUTED(e, "nbe_get_radius");
+    NBE_GUARDED(get_radius_impl(NBE_FIRST(e), radius, n_alive_out))
+}
+extern "C" int nbe_accel(nbe_engine* e, double* acc_xyz, uint8_t* alive_out)
+{
+    NBE_NOT_DISTRIBUTED(e, "nbe_accel");
+    NBE_GUARDED(accel_impl(NBE_FIRST(e), acc_xyz, alive_out))
+}
+extern "C" int nbe_tree_nodes(nbe_engine* e, double* out, size_t cap, size_t* count)
+{
+    NBE_NOT_DISTRIBUTED(e, "nbe_tree_nodes");
+    NBE_GUARDED(tree_nodes_impl(NBE_FIRST(e), out, cap, count))
+}

@@ -203,6 +203,10 @@ int multi_step(nbe_engine* e, int nsteps);
 int multi_sync(nbe_engine* e);
 int multi_set_radius(nbe_engine* e, const double* radius);
 nbe_engine* multi_first(nbe_engine* e);          // the engine of the first GPU (reads are served from it)
+bool multi_is_distributed(const nbe_engine* e);  // cfg.distributed: no GPU holds all bodies, reads are gathered
+int multi_dist_download(nbe_engine* e, double* pos, double* vel, double* mass, uint64_t* id, size_t* n_alive_out);
+int multi_dist_energy(nbe_engine* e, double* ke, double* pe, double mom[3]);
+int multi_dist_stats(nbe_engine* e, nbe_stats_t* out);
 // dist.hip
 void dist_destroy(nbe_engine* e);
 // engine.hip

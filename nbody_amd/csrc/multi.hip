@@ -9,8 +9,93 @@
 // inside a step.
 #include "engine_internal.h"
 
+#include <algorithm>
+#include <cstring>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <new>
+#include <string>
+#include <thread>
 #include <vector>
+
+// One host thread per GPU for the distributed tree: every nbe_dist_* call ends by waiting for its GPU, so a single thread
+// would run the GPUs one after the other.  run(f) calls f(r) on thread r for every r and returns the first failure; the
+// failing thread's message is carried over to the caller's (messages are per thread).
+struct Workers {
+    std::vector<std::thread> threads;
+    std::mutex mu;
+    std::condition_variable go, done;
+    std::function<int(int)> job;
+    unsigned long long generation = 0;
+    int pending = 0;
+    bool stop = false;
+    int first_rc = NBE_OK;
+    std::string first_msg;
+
+    void start(int n)
+    {
+        for (int r = 0; r < n; r++)
+            threads.emplace_back([this, r]() {
+                unsigned long long seen = 0;
+                for (;;) {
+                    std::function<int(int)> f;
+                    {
+                        std::unique_lock<std::mutex> lk(mu);
+                        go.wait(lk, [&] { return stop || generation != seen; });
+                        if (stop) return;
+                        seen = generation;
+                        f = job;
+                    }
+                    const int rc = f(r);
+                    {
+                        std::lock_guard<std::mutex> lk(mu);
+                        if (rc != NBE_OK && first_rc == NBE_OK) { first_rc = rc; first_msg = nbe_last_error(); }
+                        if (--pending == 0) done.notify_all();
+                    }
+                }
+            });
+    }
+    int run(std::function<int(int)> f)
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        job = std::move(f);
+        pending = (int)threads.size();
+        first_rc = NBE_OK;
+        generation++;
+        go.notify_all();
+        done.wait(lk, [&] { return pending == 0; });
+        if (first_rc != NBE_OK) nbe_set_error("%s", first_msg.c_str());
+        return first_rc;
+    }
+    ~Workers()
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            stop = true;
+        }
+        go.notify_all();
+        for (std::thread& t : threads) t.join();
+    }
+};
+
+// State of the distributed tree behind one handle (cfg.distributed): what disttree.py keeps per step, for all GPUs.
+struct DistMulti {
+    Workers pool;
+    size_t n_total = 0;
+    std::vector<uint64_t> ids;                       // upload order
+    std::vector<size_t> capacity;
+    std::vector<nbe_dist_buffers_t> bufs;
+    std::vector<std::vector<uint32_t>> send;         // [from][to] migrating bodies
+    std::vector<std::vector<nbe_fragment_t>> frags;
+    std::vector<std::vector<double>> boxes;          // [rank][NBE_DIST_MAX_BOXES * 6]
+    std::vector<int> nboxes, nfrags;
+    std::vector<uint64_t> live;
+    std::vector<std::vector<int32_t>> sizes;         // [from][to * nfrags[from] + f]
+    std::vector<std::vector<uint64_t>> offsets;      // [from][to]
+    bool prepared = false, want_rebalance = false;
+    int rebalances = 0;
+};
 
 struct MultiState {
     std::vector<nbe_engine*> subs;
@@ -20,6 +105,7 @@ struct MultiState {
     std::vector<hipEvent_t> pulled;          // engine r: it has finished copying the other ranges (recorded on its stream)
     std::vector<hipStream_t> side;           // engine r: stream of its velocity copies (tree mode: they run beside the key sort)
     std::vector<hipEvent_t> vel_done;        // engine r: its velocity copies have landed (recorded on side[r])
+    DistMulti* dist = nullptr;               // cfg.distributed: the bodies are not replicated
 };
 
 nbe_engine* multi_first(nbe_engine* e) { return e->multi->subs[0]; }
@@ -55,6 +141,7 @@ void multi_destroy(nbe_engine* e)
             if (r < m->side.size() && m->side[r]) (void)hipStreamDestroy(m->side[r]);
             if (m->subs[r]) nbe_destroy(m->subs[r]);
         }
+        delete m->dist;
         delete m;
     }
     delete e;
@@ -66,6 +153,10 @@ int multi_create(const nbe_config* cfg, nbe_engine** out)
     if (G > 64) { nbe_set_error("num_devices %d: at most 64", G); return NBE_E_INVALID; }
     if (cfg->collisions && cfg->mode != NBE_MODE_TREE) {
         nbe_set_error("collisions with num_devices > 1 need tree mode");
+        return NBE_E_UNSUPPORTED;
+    }
+    if (cfg->distributed && (cfg->mode != NBE_MODE_TREE || cfg->collisions || cfg->reference_quirks || cfg->walk_criterion != NBE_WALK_PER_BODY)) {
+        nbe_set_error("distributed = 1 needs tree mode, collisions off, the per-body criterion and no reference_quirks");
         return NBE_E_UNSUPPORTED;
     }
     nbe_engine* e = new (std::nothrow) nbe_engine();
@@ -85,6 +176,7 @@ int multi_create(const nbe_config* cfg, nbe_engine** out)
         nbe_config sub = *cfg;
         sub.num_devices = 1;
         sub.device_ids = nullptr;
+        sub.distributed = 0;
         sub.device = m->devs[(size_t)r];
         rc = nbe_create(&sub, &m->subs[(size_t)r]);
         if (rc != NBE_OK) break;
@@ -114,13 +206,249 @@ int multi_create(const nbe_config* cfg, nbe_engine** out)
         nbe_set_error("%s", msg);
         return rc;
     }
+    if (cfg->distributed) {
+        m->dist = new (std::nothrow) DistMulti();
+        if (!m->dist) { multi_destroy(e); nbe_set_error("out of host memory"); return NBE_E_NOMEM; }
+        m->dist->pool.start(G);
+    }
     *out = e;
+    return NBE_OK;
+}
+
+bool multi_is_distributed(const nbe_engine* e) { return e->multi && e->multi->dist; }
+
+// ---- the distributed tree on the engine's GPUs --------------------------------------------------------------------
+// Splitters from every GPU's evenly spaced sorted keys: a sample of GPU r stands for live[r] / samples bodies; the k-th
+// splitter is the key where the running weight passes k/G of all bodies (a splitter is a key: equal keys stay together).
+static std::vector<uint64_t> choose_splitters(const std::vector<std::vector<uint64_t>>& samples, const std::vector<size_t>& live)
+{
+    const size_t G = samples.size();
+    std::vector<std::pair<uint64_t, double>> all;
+    for (size_t r = 0; r < G; r++)
+        for (uint64_t k : samples[r]) all.push_back({k, (double)live[r] / (double)samples[r].size()});
+    std::stable_sort(all.begin(), all.end(), [](const std::pair<uint64_t, double>& a, const std::pair<uint64_t, double>& b) { return a.first < b.first; });
+    std::vector<uint64_t> split(G + 1, 0);
+    split[G] = 1ull << 63;
+    if (all.empty()) {
+        for (size_t k = 1; k < G; k++) split[k] = split[G];
+        return split;
+    }
+    double total = 0;
+    for (const auto& a : all) total += a.second;
+    double run = 0;
+    size_t j = 0;
+    for (size_t k = 1; k < G; k++) {
+        const double want = total * (double)k / (double)G;
+        while (j + 1 < all.size() && run + all[j].second < want) { run += all[j].second; j++; }
+        split[k] = std::max(all[j].first, split[k - 1]);
+    }
+    return split;
+}
+
+static int dist_distribute(nbe_engine* e)
+{
+    MultiState* m = e->multi;
+    DistMulti* d = m->dist;
+    const size_t G = m->subs.size();
+    std::vector<std::vector<uint64_t>> samples(G);
+    std::vector<size_t> live(G, 0);
+    NBE_TRY(d->pool.run([&](int r) -> int {
+        samples[(size_t)r].assign(4096, 0);
+        size_t got = 0;
+        NBE_TRY(nbe_dist_sample_keys(m->subs[(size_t)r], 4096, samples[(size_t)r].data(), &got, &live[(size_t)r]));
+        samples[(size_t)r].resize(got);
+        return NBE_OK;
+    }));
+    const std::vector<uint64_t> split = choose_splitters(samples, live);
+    return d->pool.run([&](int r) -> int { return nbe_dist_set_splitters(m->subs[(size_t)r], split.data()); });
+}
+
+static int dist_upload(nbe_engine* e, size_t n, const double* pos, const double* vel, const double* mass, const uint64_t* id)
+{
+    MultiState* m = e->multi;
+    DistMulti* d = m->dist;
+    const size_t G = m->subs.size();
+    const size_t per = (n + G - 1) / G;
+    e->n = 0;
+    d->prepared = false; d->want_rebalance = false;
+    d->n_total = n;
+    d->ids.resize(n);
+    for (size_t i = 0; i < n; i++) d->ids[i] = id ? id[i] : (uint64_t)i;
+    d->capacity.assign(G, per + per / 4 + 4096);     // room for a quarter more than an even share
+    d->bufs.assign(G, nbe_dist_buffers_t{});
+    NBE_TRY(d->pool.run([&](int r) -> int {
+        const size_t a = std::min(n, (size_t)r * per), z = std::min(n, ((size_t)r + 1) * per);
+        NBE_TRY(nbe_dist_upload(m->subs[(size_t)r], r, (int)G, d->capacity[(size_t)r], z - a, pos + 3 * a, vel + 3 * a, mass + a, a));
+        return nbe_dist_buffers(m->subs[(size_t)r], &d->bufs[(size_t)r]);
+    }));
+    NBE_TRY(dist_distribute(e));
+    e->n = n;
+    return NBE_OK;
+}
+
+// Everything of a step but the force pass (what DistributedTree._prepare does in nbody_amd/disttree.py).
+static int dist_prepare(nbe_engine* e)
+{
+    MultiState* m = e->multi;
+    DistMulti* d = m->dist;
+    const size_t G = m->subs.size();
+    if (d->want_rebalance) {
+        NBE_TRY(dist_distribute(e));
+        d->rebalances++;
+        d->want_rebalance = false;
+    }
+    // bodies that crossed a splitter go to their new owner
+    d->send.assign(G, std::vector<uint32_t>(G, 0));
+    NBE_TRY(d->pool.run([&](int r) -> int { return nbe_dist_classify(m->subs[(size_t)r], d->send[(size_t)r].data()); }));
+    d->frags.assign(G, std::vector<nbe_fragment_t>(NBE_DIST_MAX_FRAGMENTS));
+    d->boxes.assign(G, std::vector<double>(NBE_DIST_MAX_BOXES * 6, 0.0));
+    d->nboxes.assign(G, 0); d->nfrags.assign(G, 0); d->live.assign(G, 0);
+    NBE_TRY(d->pool.run([&](int qi) -> int {
+        const size_t q = (size_t)qi;
+        nbe_engine* sub = m->subs[q];
+        NBE_HIP(hipSetDevice(m->devs[q]));
+        const size_t rec = d->bufs[q].record_bytes;
+        size_t at = 0;
+        for (size_t r = 0; r < G; r++) {
+            const size_t k = d->send[r][q];
+            if (!k) continue;
+            size_t off = 0;
+            for (size_t t = 0; t < q; t++) off += d->send[r][t];
+            if (at + k > d->bufs[q].slots) { nbe_set_error("GPU %zu: %zu bodies arrive, its inbox holds %llu", q, at + k, (unsigned long long)d->bufs[q].slots); return NBE_E_NOMEM; }
+            NBE_HIP(hipMemcpyPeerAsync((char*)d->bufs[q].inbox + at * rec, m->devs[q], (const char*)d->bufs[r].outbox + off * rec, m->devs[r],
+                                       k * rec, sub->stream));
+            at += k;
+        }
+        NBE_TRY(nbe_dist_receive(sub, at));
+        return nbe_dist_build(sub, d->frags[q].data(), NBE_DIST_MAX_FRAGMENTS, &d->nfrags[q], d->boxes[q].data(), &d->nboxes[q], &d->live[q]);
+    }));
+    // every GPU needs every GPU's fragment roots and boxes
+    std::vector<nbe_fragment_t> all;
+    std::vector<double> boxes(G * NBE_DIST_MAX_BOXES * 6, 0.0);
+    uint64_t total_live = 0, most = 0;
+    double fill = 0;
+    for (size_t r = 0; r < G; r++) {
+        all.insert(all.end(), d->frags[r].begin(), d->frags[r].begin() + d->nfrags[r]);
+        std::copy(d->boxes[r].begin(), d->boxes[r].end(), boxes.begin() + (long)(r * NBE_DIST_MAX_BOXES * 6));
+        total_live += d->live[r];
+        most = std::max(most, d->live[r]);
+        fill = std::max(fill, (double)d->live[r] / (double)d->capacity[r]);
+    }
+    // new splitters before the next step when a GPU holds a tenth more than its share or has filled nine tenths of its slots
+    d->want_rebalance = total_live > 0 && ((double)most > 1.10 * (double)total_live / (double)G + 64.0 || fill > 0.9);
+    d->sizes.assign(G, std::vector<int32_t>());
+    d->offsets.assign(G, std::vector<uint64_t>(G + 1, 0));
+    NBE_TRY(d->pool.run([&](int r) -> int {
+        d->sizes[(size_t)r].assign(G * (size_t)std::max(d->nfrags[(size_t)r], 1), 0);
+        return nbe_dist_export(m->subs[(size_t)r], all.data(), d->nfrags.data(), boxes.data(), d->nboxes.data(), d->sizes[(size_t)r].data(),
+                               d->offsets[(size_t)r].data());
+    }));
+    NBE_TRY(d->pool.run([&](int qi) -> int {
+        const size_t q = (size_t)qi;
+        nbe_engine* sub = m->subs[q];
+        NBE_HIP(hipSetDevice(m->devs[q]));
+        const size_t nb = d->bufs[q].node_bytes;
+        std::vector<uint64_t> import_offsets(G, 0);
+        std::vector<int32_t> import_sizes;
+        size_t at = 0;
+        for (size_t r = 0; r < G; r++) {
+            import_offsets[r] = at;
+            const size_t nf = (size_t)d->nfrags[r];
+            for (size_t f = 0; f < nf; f++) import_sizes.push_back(r == q ? 0 : d->sizes[r][q * nf + f]);
+            if (r == q) continue;
+            const size_t k = (size_t)(d->offsets[r][q + 1] - d->offsets[r][q]);
+            if (!k) continue;
+            if (at + k > d->bufs[q].import_cap) { nbe_set_error("GPU %zu: %zu nodes arrive, its import buffer holds %llu", q, at + k, (unsigned long long)d->bufs[q].import_cap); return NBE_E_NOMEM; }
+            NBE_HIP(hipMemcpyPeerAsync((char*)d->bufs[q].import_nodes + at * nb, m->devs[q],
+                                       (const char*)d->bufs[r].export_nodes + (size_t)d->offsets[r][q] * nb, m->devs[r], k * nb, sub->stream));
+            at += k;
+        }
+        if (import_sizes.empty()) import_sizes.push_back(0);
+        return nbe_dist_assemble(sub, import_sizes.data(), import_offsets.data());
+    }));
+    d->prepared = true;
+    return NBE_OK;
+}
+
+static int dist_step(nbe_engine* e, int nsteps)
+{
+    MultiState* m = e->multi;
+    DistMulti* d = m->dist;
+    for (int s = 0; s < nsteps; s++) {
+        if (!d->prepared) NBE_TRY(dist_prepare(e));
+        NBE_TRY(d->pool.run([&](int r) -> int { return nbe_dist_advance(m->subs[(size_t)r]); }));
+        d->prepared = false;
+    }
+    return NBE_OK;
+}
+
+int multi_dist_download(nbe_engine* e, double* pos, double* vel, double* mass, uint64_t* id, size_t* n_alive_out)
+{
+    MultiState* m = e->multi;
+    DistMulti* d = m->dist;
+    const size_t G = m->subs.size();
+    std::vector<std::vector<uint64_t>> idx(G);
+    std::vector<std::vector<double>> p(G), v(G), ms(G);
+    std::vector<size_t> cnt(G, 0);
+    NBE_TRY(d->pool.run([&](int r) -> int {
+        const size_t cap = d->capacity[(size_t)r];
+        idx[(size_t)r].resize(cap); p[(size_t)r].resize(3 * cap); v[(size_t)r].resize(3 * cap); ms[(size_t)r].resize(cap);
+        return nbe_dist_download(m->subs[(size_t)r], idx[(size_t)r].data(), p[(size_t)r].data(), v[(size_t)r].data(), ms[(size_t)r].data(), &cnt[(size_t)r]);
+    }));
+    // survivors in upload order, as one engine returns them
+    std::vector<std::pair<uint64_t, std::pair<uint32_t, uint32_t>>> where;
+    for (size_t r = 0; r < G; r++)
+        for (size_t k = 0; k < cnt[r]; k++) where.push_back({idx[r][k], {(uint32_t)r, (uint32_t)k}});
+    std::sort(where.begin(), where.end());
+    for (size_t o = 0; o < where.size(); o++) {
+        const size_t r = where[o].second.first, k = where[o].second.second;
+        for (int c = 0; c < 3; c++) {
+            if (pos) pos[3 * o + (size_t)c] = p[r][3 * k + (size_t)c];
+            if (vel) vel[3 * o + (size_t)c] = v[r][3 * k + (size_t)c];
+        }
+        if (mass) mass[o] = ms[r][k];
+        if (id) id[o] = where[o].first < d->ids.size() ? d->ids[where[o].first] : where[o].first;
+    }
+    if (n_alive_out) *n_alive_out = where.size();
+    return NBE_OK;
+}
+
+int multi_dist_energy(nbe_engine* e, double* ke, double* pe, double mom[3])
+{
+    MultiState* m = e->multi;
+    DistMulti* d = m->dist;
+    const size_t G = m->subs.size();
+    if (e->n == 0) { if (ke) *ke = 0; if (pe) *pe = 0; if (mom) mom[0] = mom[1] = mom[2] = 0; return NBE_OK; }
+    if (!d->prepared) NBE_TRY(dist_prepare(e));
+    std::vector<double> part(G * 5, 0.0);
+    NBE_TRY(d->pool.run([&](int r) -> int { return nbe_dist_energy(m->subs[(size_t)r], &part[5 * (size_t)r], &part[5 * (size_t)r + 1], &part[5 * (size_t)r + 2]); }));
+    double tot[5] = {0, 0, 0, 0, 0};
+    for (size_t r = 0; r < G; r++)
+        for (int k = 0; k < 5; k++) tot[k] += part[5 * r + (size_t)k];
+    if (ke) *ke = tot[0];
+    if (pe) *pe = tot[1];
+    if (mom) { mom[0] = tot[2]; mom[1] = tot[3]; mom[2] = tot[4]; }
+    return NBE_OK;
+}
+
+int multi_dist_stats(nbe_engine* e, nbe_stats_t* out)
+{
+    MultiState* m = e->multi;
+    memset(out, 0, sizeof(*out));
+    out->n = m->dist->n_total;
+    for (nbe_engine* s : m->subs) {
+        out->n_alive += s->stats.n_alive;
+        out->tree_nodes += s->stats.tree_nodes;
+        out->tree_cells += s->stats.tree_cells;
+    }
+    out->steps = m->subs[0]->stats.steps;
     return NBE_OK;
 }
 
 int multi_upload(nbe_engine* e, size_t n, const double* pos, const double* vel, const double* mass, const uint64_t* id)
 {
     MultiState* m = e->multi;
+    if (m->dist) return dist_upload(e, n, pos, vel, mass, id);
     const size_t G = m->subs.size();
     ranges(n, G, &m->first, &m->count);
     e->n = 0;                                   // until every engine holds the new bodies
@@ -149,6 +477,7 @@ int multi_step(nbe_engine* e, int nsteps)
     MultiState* m = e->multi;
     const size_t G = m->subs.size();
     if (e->n == 0) return NBE_OK;
+    if (m->dist) return dist_step(e, nsteps);
     for (int step = 0; step < nsteps; step++) {
         // sort + build on every GPU (replicated, identical results); also sends the frame of this step from GPU 0
         for (size_t r = 0; r < G; r++) NBE_TRY(nbe_shard_prepare(m->subs[r]));

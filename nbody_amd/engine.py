@@ -35,7 +35,7 @@ class Config(C.Structure):
                 ("dt", C.c_double), ("eps", C.c_double), ("bound_center", C.c_double * 3),
                 ("bound_width", C.c_double), ("device", C.c_int), ("collisions", C.c_int),
                 ("reference_quirks", C.c_int), ("walk_criterion", C.c_int), ("num_devices", C.c_int),
-                ("cell_sums", C.c_int), ("device_ids", C.POINTER(C.c_int))]
+                ("cell_sums", C.c_int), ("device_ids", C.POINTER(C.c_int)), ("distributed", C.c_int)]
 
 
 class Stats(C.Structure):
@@ -121,7 +121,7 @@ class Engine:
 
     def __init__(self, mode="direct", precision="f32", theta=None, dt=None, eps=None, G=None,
                  bound_center=None, bound_width=None, device=0, collisions=False, ref_com=False,
-                 drop_tail=False, per_wave=False, devices=None, tree_sums=False):
+                 drop_tail=False, per_wave=False, devices=None, tree_sums=False, distributed=False):
         """devices: a list of HIP device ordinals; with more than one the engine itself drives all of them from this
         process (targets split into contiguous ranges, ranges copied between the GPUs every step); the same ordinal
         may appear more than once.
@@ -150,6 +150,8 @@ class Engine:
             cfg.num_devices = len(devices)
             cfg.device_ids = C.cast(ids, C.POINTER(C.c_int))
         cfg.cell_sums = 1 if tree_sums else 0
+        # several devices: every body on one GPU only, pruned subtrees exchanged (instead of all bodies on every GPU)
+        cfg.distributed = 1 if distributed else 0
         cfg.collisions = int(bool(collisions))      # False = the reference's -nocollision run (main.go:24)
         # the reference's running "centre of mass" (tree.go:189-193) and its unwalked last n mod 4 bodies
         # (main.go:134-148), for number-for-number comparisons with the Go program

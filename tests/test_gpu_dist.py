@@ -278,3 +278,39 @@ def test_one_rank_over_rccl(gpu):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("precision,n,devices", [("f32", 20001, [0, 0, 0]), ("f64", 5003, [0, 0]), ("f32", 100000, [0] * 8)])
+def test_distributed_tree_behind_one_engine_handle(gpu, precision, n, devices):
+    """nbe_config.distributed with num_devices > 1: the engine itself runs the distributed tree on its GPUs (one host
+    thread each, peer copies for the exchanges; here several shards on one GPU).  Upload, steps, download, statistics and
+    energies through the ordinary calls; the state equals one engine's bit for bit."""
+    b = physics.plummer(n, seed=8, a=2e3)
+    with Engine(mode="tree", precision=precision, theta=0.6, devices=devices, distributed=True) as e:
+        e.upload(b.pos, b.vel, b.mass, ids=np.arange(n, dtype=np.uint64) + 1000)
+        e.step(2)
+        ke, pe, mom = e.energy()
+        e.step(2)
+        p, v, m, ids = e.download()
+        st = e.stats()
+        for call in (e.accel, e.tree_nodes, e.step_timed, lambda: e.time_force_kernel(1)):
+            with pytest.raises(EngineError, match="distributed = 1|num_devices"):
+                call()
+    assert st.n == n and st.n_alive == n and st.steps == 4
+    want = run_one(b, 4, precision=precision, theta=0.6)
+    assert np.array_equal(ids, want[0] + 1000)
+    assert np.array_equal(p, want[1]) and np.array_equal(v, want[2]) and np.array_equal(m, want[3])
+    with Engine(mode="tree", precision=precision, theta=0.6, tree_sums=True) as one:
+        one.upload(b.pos, b.vel, b.mass)
+        one.step(2)
+        ke1, pe1, mom1 = one.energy()              # (the exact pair sum at these sizes; the distributed run sums over accepted nodes)
+    assert abs(ke - ke1) <= 1e-6 * ke1 and abs(pe - pe1) <= 5e-3 * abs(pe1)
+
+
+def test_distributed_needs_several_devices_and_tree_mode(gpu):
+    with pytest.raises(EngineError, match="num_devices > 1"):
+        Engine(mode="tree", distributed=True)
+    with pytest.raises(EngineError, match="needs tree mode"):
+        Engine(mode="direct", devices=[0, 0], distributed=True)
+    with pytest.raises(EngineError, match="needs tree mode"):
+        Engine(mode="tree", devices=[0, 0], distributed=True, collisions=True)
