@@ -10,7 +10,12 @@
 
 static double frand(unsigned *s) { *s = *s * 1664525u + 1013904223u; return (double)(*s >> 8) / 16777216.0; }
 
-static int run(int mode, int precision, int shards, double *pos_out, double *vel_out)
+/* distributed: 0 = every shard holds all bodies; 1 = every body on one shard only (cfg.distributed; one shard: the
+ * same cell sums on one engine, cfg.cell_sums = NBE_SUMS_TREE, which is what a distributed run must reproduce) */
+static int run_as(int mode, int precision, int shards, int distributed, double *pos_out, double *vel_out);
+static int run(int mode, int precision, int shards, double *pos_out, double *vel_out) { return run_as(mode, precision, shards, 0, pos_out, vel_out); }
+
+static int run_as(int mode, int precision, int shards, int distributed, double *pos_out, double *vel_out)
 {
     static double pos[3 * N], vel[3 * N], mass[N];
     static const int ids[4] = {0, 0, 0, 0};
@@ -28,7 +33,8 @@ static int run(int mode, int precision, int shards, double *pos_out, double *vel
     pos[3 * 77] = 32767.9; vel[3 * 77] = 1.0;          /* leaves the bound in the first step (tree mode removes it) */
     if (nbe_default_config(&cfg) != NBE_OK) return 20;
     cfg.mode = mode; cfg.precision = precision; cfg.theta = 0.6;
-    if (shards > 1) { cfg.num_devices = shards; cfg.device_ids = ids; }
+    if (shards > 1) { cfg.num_devices = shards; cfg.device_ids = ids; cfg.distributed = distributed; }
+    else if (distributed) cfg.cell_sums = NBE_SUMS_TREE;
     if (nbe_create(&cfg, &e) != NBE_OK) { printf("create: %s\n", nbe_last_error()); return 21; }
     if (nbe_upload(e, N, pos, vel, mass, NULL) != NBE_OK) { printf("upload: %s\n", nbe_last_error()); return 22; }
     if (nbe_step(e, 7) != NBE_OK) { printf("step: %s\n", nbe_last_error()); return 23; }
@@ -51,6 +57,13 @@ int main(void)
         for (shards = 2; shards <= 4; shards++) {
             if ((rc = run(NBE_MODE_TREE, precisions[k], shards, p2, v2)) != 0) return rc;
             if (memcmp(p1, p2, sizeof(p1)) != 0 || memcmp(v1, v2, sizeof(v1)) != 0) { printf("tree precision %d, %d shards differ from one\n", precisions[k], shards); return 30; }
+        }
+    }
+    for (k = 0; k < 3; k += 2) {       /* fp32 and fp64: the distributed tree equals one engine bit for bit */
+        if ((rc = run_as(NBE_MODE_TREE, precisions[k], 1, 1, p1, v1)) != 0) return rc;
+        for (shards = 2; shards <= 4; shards++) {
+            if ((rc = run_as(NBE_MODE_TREE, precisions[k], shards, 1, p2, v2)) != 0) return rc;
+            if (memcmp(p1, p2, sizeof(p1)) != 0 || memcmp(v1, v2, sizeof(v1)) != 0) { printf("distributed tree, precision %d, %d shards differ from one\n", precisions[k], shards); return 32; }
         }
     }
     if ((rc = run(NBE_MODE_DIRECT, NBE_PREC_F32, 1, p1, v1)) != 0) return rc;
