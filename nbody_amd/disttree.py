@@ -227,9 +227,14 @@ class LocalComm:
         """per_rank[r] = numpy array of rank r; every rank receives the list of all of them."""
         return [list(per_rank) for _ in range(self.world)]
 
-    def alltoall(self, ranks, which_send, which_recv, send_counts, unit):
+    def allgather_many(self, per_rank):
+        """per_rank[r] = list of numpy arrays of rank r; every rank receives the list (over ranks) of those lists."""
+        return [[list(a) for a in per_rank] for _ in range(self.world)]
+
+    def alltoall(self, ranks, which_send, which_recv, send_counts, unit, recv_counts=None):
         """send_counts[r][q] units of `unit` bytes go from rank r's `which_send` buffer (destination after destination)
-        to rank q's `which_recv` buffer (source after source).  Returns recv_counts[q][r]."""
+        to rank q's `which_recv` buffer (source after source).  Returns recv_counts[q][r] (recv_counts, when the caller
+        knows them already, saves a communicator with separate processes one exchange)."""
         W = self.world
         recv = [[int(send_counts[r][q]) for r in range(W)] for q in range(W)]
         for q in range(W):
@@ -259,30 +264,52 @@ class TorchComm:
         self.device = torch.device("cuda", torch.cuda.current_device()) if self.backend == "nccl" else torch.device("cpu")
 
     def allgather(self, per_rank):
-        mine = np.ascontiguousarray(per_rank[0])
-        raw = torch.from_numpy(mine.view(np.uint8).reshape(-1).copy())
-        sizes = torch.zeros(self.world, dtype=torch.int64, device=self.device)
-        dist.all_gather_into_tensor(sizes, torch.tensor([raw.numel()], dtype=torch.int64, device=self.device), group=self.group)
-        sizes = sizes.cpu().tolist()
-        cap = max(max(sizes), 1)
-        buf = torch.zeros(cap, dtype=torch.uint8, device=self.device)
-        buf[:raw.numel()] = raw.to(self.device)
-        out = torch.zeros(self.world * cap, dtype=torch.uint8, device=self.device)
-        dist.all_gather_into_tensor(out, buf, group=self.group)
-        out = out.cpu().numpy()
+        return [[got[0] for got in self.allgather_many([[per_rank[0]]])[0]]]
+
+    def allgather_many(self, per_rank):
+        """One collective for several small arrays: every rank sends [total bytes | byte length of each array | the
+        arrays], padded to a capacity that all ranks hold alike; a rank that sees a longer message from anybody doubles
+        the capacity (everybody sees the same lengths, so everybody does) and the exchange is repeated."""
+        arrays = [np.ascontiguousarray(a) for a in per_rank[0]]
+        blobs = [a.view(np.uint8).reshape(-1) for a in arrays]
+        head = np.array([0] + [b.size for b in blobs], dtype=np.int64)
+        head[0] = 8 * head.size + int(head[1:].sum())
+        msg = np.concatenate([head.view(np.uint8)] + blobs)
+        cap = getattr(self, "_cap", 1 << 16)
+        while True:
+            send = torch.zeros(cap, dtype=torch.uint8)
+            k = min(cap, msg.size)
+            send[:k] = torch.from_numpy(msg[:k].copy())
+            out = torch.zeros(self.world * cap, dtype=torch.uint8, device=self.device)
+            dist.all_gather_into_tensor(out, send.to(self.device), group=self.group)
+            out = out.cpu().numpy().reshape(self.world, cap)
+            need = int(max(out[r, :8].view(np.int64)[0] for r in range(self.world)))
+            if need <= cap:
+                break
+            cap = 2 * need
+        self._cap = cap
         res = []
         for r in range(self.world):
-            a = out[r * cap:r * cap + sizes[r]].copy().view(mine.dtype)
-            res.append(a.reshape((-1,) + mine.shape[1:]) if mine.ndim > 1 else a)
+            lens = out[r, 8:8 * head.size].view(np.int64)
+            at = 8 * head.size
+            got = []
+            for a, n in zip(arrays, lens):
+                raw = out[r, at:at + int(n)].copy().view(a.dtype)
+                got.append(raw.reshape((-1,) + a.shape[1:]) if a.ndim > 1 else raw)
+                at += int(n)
+            res.append(got)
         return [res]
 
-    def alltoall(self, ranks, which_send, which_recv, send_counts, unit):
+    def alltoall(self, ranks, which_send, which_recv, send_counts, unit, recv_counts=None):
         me = ranks[0]
-        sc = torch.tensor([int(c) for c in send_counts[0]], dtype=torch.int64, device=self.device)
-        rc = torch.zeros_like(sc)
-        dist.all_to_all_single(rc, sc, group=self.group)
-        rc = rc.cpu().tolist()
-        sc = sc.cpu().tolist()
+        sc = [int(c) for c in send_counts[0]]
+        if recv_counts is None:
+            t = torch.tensor(sc, dtype=torch.int64, device=self.device)
+            rc = torch.zeros_like(t)
+            dist.all_to_all_single(rc, t, group=self.group)
+            rc = rc.cpu().tolist()
+        else:
+            rc = [int(c) for c in recv_counts[0]]
         src, dst = me.bytes_view(which_send), me.bytes_view(which_recv)
         ns, nr = sum(sc) * unit, sum(rc) * unit
         if nr > dst.numel():
@@ -408,12 +435,12 @@ class DistributedTree:
         # every rank's own tree; the roots of its fragments and its bounding box go to everybody
         built = [r.build() for r in R]
         self._mark("sort_build")
-        frags = self.comm.allgather([b[0] for b in built])
-        # (the number of bodies rides with the boxes: every rank sees every rank's, and all take the same decision)
-        boxes = self.comm.allgather([np.concatenate([b[1].reshape(-1), [float(b[2]), float(r.capacity)]]) for b, r in zip(built, R)])
-        self.lives = [int(a[-2]) for a in boxes[0]]
-        fill = max(a[-2] / a[-1] for a in boxes[0])
-        boxes = [[a[:-2].reshape(-1, 6) for a in per_rank] for per_rank in boxes]
+        # (one collective; the number of bodies rides along: every rank sees every rank's, and all take the same decision)
+        got = self.comm.allgather_many([[b[0], b[1].reshape(-1), np.array([b[2], r.capacity], dtype=np.int64)] for b, r in zip(built, R)])
+        frags = [[g[0] for g in per_rank] for per_rank in got]
+        boxes = [[g[1].reshape(-1, 6) for g in per_rank] for per_rank in got]
+        self.lives = [int(g[2][0]) for g in got[0]]
+        fill = max(g[2][0] / g[2][1] for g in got[0])
         if self.rebalance_at is not None and sum(self.lives) > 0:
             mean = sum(self.lives) / W
             self._want_rebalance = max(self.lives) > self.rebalance_at * mean + 64 or fill > 0.9
@@ -426,10 +453,13 @@ class DistributedTree:
         # pruned fragments to those who need them, and how large each came out
         node_bytes = R[0].buffers.node_bytes
         sendn = [np.diff(ex[0][1].astype(np.int64)) for ex in exported]
-        recvn = self.comm.alltoall(R, "export", "import", sendn, node_bytes)
+        got = self.comm.allgather_many([[ex[0][0].reshape(-1), ex[0][1].astype(np.int64)] for ex in exported])
+        sizes = [[g[0] for g in per_rank] for per_rank in got]
+        # what every rank exports to this one follows from everybody's offsets: no exchange of counts
+        recvn = [[int(got[k][src][1][r.rank + 1] - got[k][src][1][r.rank]) for src in range(W)] for k, r in enumerate(R)]
+        self.comm.alltoall(R, "export", "import", sendn, node_bytes, recv_counts=recvn)
         self.last_import_nodes = [int(sum(rc)) for rc in recvn]
         self.last_migrated = [int(sum(rc)) for rc in recv]
-        sizes = self.comm.allgather([ex[0][0].reshape(-1) for ex in exported])
         for k, r in enumerate(R):
             counts = exported[k][1]
             imp = []

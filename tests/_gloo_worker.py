@@ -82,6 +82,26 @@ def main():
     out_prefix, mode, n, nsteps, kind = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    if kind == "comm":
+        # the host-side collectives of the distributed tree, on the CPU: ragged arrays, a message longer than the first capacity
+        from nbody_amd.disttree import TorchComm
+        comm = TorchComm()
+        rng = np.random.default_rng(100 + rank)
+        a = rng.integers(0, 1 << 60, 5 + 3 * rank, dtype=np.int64)
+        b2 = rng.normal(size=(rank + 1, 6))
+        big = rng.integers(0, 255, 70000 * (rank + 1), dtype=np.uint8)       # beyond the 64 KiB the exchange starts with
+        first = comm.allgather_many([[a, b2]])[0]
+        second = comm.allgather_many([[a, b2, big]])[0]
+        third = comm.allgather([b2])[0]
+        out = {}
+        for r in range(world):
+            out[f"a{r}"], out[f"b{r}"] = first[r]
+            out[f"c{r}"], out[f"d{r}"], out[f"big{r}"] = second[r]
+            out[f"e{r}"] = third[r]
+        np.savez(f"{out_prefix}.rank{rank}.npz", cap=comm._cap, **out)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     bodies = physics.makebodies(n - 2, seed=11)
     if kind == "dist":
         # key-range-distributed tree: this rank starts with its slice of the upload order, all ranks share cuda:0

@@ -87,3 +87,20 @@ def test_two_ranks_reproduce_single_process(tmp_path, mode, n, split):
         vel = vel + f / b.mass[:, None] * 3600.0
         pos = pos + vel * 3600.0
     assert np.array_equal(res[0]["pos"], pos) and np.array_equal(res[0]["vel"], vel)
+
+
+def test_ragged_allgather_of_the_distributed_tree(tmp_path):
+    """TorchComm.allgather_many over gloo, three ranks: arrays of different lengths per rank come back whole on every rank,
+    in one collective while they fit the agreed capacity, and the capacity grows when a message does not."""
+    world = 3
+    res = run_ranks(tmp_path, world, ["-", "0", "0", "comm"])
+    for r in range(world):
+        rng = np.random.default_rng(100 + r)
+        a = rng.integers(0, 1 << 60, 5 + 3 * r, dtype=np.int64)
+        b = rng.normal(size=(r + 1, 6))
+        big = rng.integers(0, 255, 70000 * (r + 1), dtype=np.uint8)
+        for got in res:
+            assert np.array_equal(got[f"a{r}"], a) and np.array_equal(got[f"c{r}"], a)
+            assert np.array_equal(got[f"b{r}"], b) and np.array_equal(got[f"d{r}"], b) and np.array_equal(got[f"e{r}"], b)
+            assert np.array_equal(got[f"big{r}"], big)
+    assert all(int(got["cap"]) >= 210000 for got in res)
