@@ -64,7 +64,7 @@ def test_cells_summed_child_by_child_equal_the_prefix_sums_to_rounding(gpu):
 
 @pytest.mark.parametrize("n,world,precision,nsteps", [(5003, 2, "f32", 5), (5003, 3, "f32", 5), (20001, 4, "f64", 4),
                                                       (300, 5, "f32", 4), (100000, 8, "f32", 3), (1001, 3, "f64", 6),
-                                                      (7, 3, "f32", 2)])
+                                                      (7, 3, "f32", 2), (2, 3, "f32", 3), (1, 2, "f64", 2)])
 def test_ranks_on_one_gpu_equal_one_engine_bit_for_bit(gpu, n, world, precision, nsteps):
     """2 to 8 ranks (uneven n, ranks with a handful of bodies) against one engine: identical survivors, positions and
     velocities after several steps, in which bodies change owner."""
@@ -314,3 +314,26 @@ def test_distributed_needs_several_devices_and_tree_mode(gpu):
         Engine(mode="direct", devices=[0, 0], distributed=True)
     with pytest.raises(EngineError, match="needs tree mode"):
         Engine(mode="tree", devices=[0, 0], distributed=True, collisions=True)
+
+
+def test_a_rank_can_be_loaded_again(gpu):
+    """nbe_dist_upload on an engine that has run before starts a new run (other capacity, other bodies)."""
+    b1, b2 = physics.plummer(3000, seed=1, a=2e3), physics.plummer(5000, seed=2, a=2e3)
+    ranks = [DistRank(r, 2, precision="f32", theta=0.6) for r in range(2)]
+    try:
+        for b in (b1, b2):
+            n = len(b)
+            for r in ranks:
+                a, z = r.rank * (n // 2), (r.rank + 1) * (n // 2)
+                r.upload(n, b.pos[a:z], b.vel[a:z], b.mass[a:z], a)
+                r.use_torch_stream()
+            dt = DistributedTree(ranks, LocalComm(2))
+            dt.distribute()
+            dt.step(3)
+            got = dt.download()
+            want = run_one(b, 3, precision="f32", theta=0.6)
+            for a, w in zip(got, want):
+                assert np.array_equal(a, w)
+    finally:
+        for r in ranks:
+            r.close()
