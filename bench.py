@@ -272,29 +272,7 @@ def main():
             return out
 
         if world > 1 or force_dist:
-            ranks = dist_ranks(world, [rank])
-            tree = DistributedTree(ranks, TorchComm())
-            tree.distribute()
-            sec = timed_steps(lambda: tree.step(1), sync, barrier, 2, 5)      # (the first step moves every body to its owner)
-            acc = {}
-            for _ in range(3):
-                for k, v in tree.step_profiled().items():
-                    acc[k] = acc.get(k, 0.0) + v / 3
-            live = float(ranks[0].engine.stats().n_alive)
-            if world > 1:
-                t = torch.tensor([sec] + [acc[k] for k in sorted(acc)], device="cuda", dtype=torch.float64)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                sec = float(t[0].item())
-                acc = {k: float(v) for k, v in zip(sorted(acc), t[1:].tolist())}
-                t = torch.tensor([live, -live], device="cuda", dtype=torch.float64)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                live = [float(t[0].item()), -float(t[1].item())]
-            extra["bh_theta0.5_fp32_plummer_16M_distributed_tree"] = {
-                "steps_per_s": 5 / sec, "ms_per_step": 1e3 * sec / 5, "phase_ms_max_over_ranks": acc,
-                "bodies_per_rank_max_min": live, "imported_nodes_this_rank": tree.last_import_nodes[0],
-                "migrated_bodies_this_rank": tree.last_migrated[0]}
-            for r in ranks:
-                r.close()
+            pass        # (one rank per GPU: measured last, under a watchdog, see distributed_tree_extra below)
         else:
             # one GPU: eight ranks side by side on it, phases drained one by one; a rank's share of the sums is what a GPU
             # of an eight-GPU run does per step (the exchanges are device copies here)
@@ -478,17 +456,84 @@ def main():
         except Exception as ex:  # the baseline must never take the benchmark down
             log("cpu tree baseline failed:", ex)
 
-    if rank == 0:
-        out = {"metric": "body-body interactions/sec", "value": value, "unit": "interactions/s", "n_gpus": world,
+
+    def distributed_tree_extra():
+        """The 16M-body cloud on the key-range-distributed tree, one rank per GPU.  It is the newest multi-process path and
+        runs last: a watchdog prints the line without it should its collectives not come back."""
+        from nbody_amd.disttree import DistRank, DistributedTree, TorchComm
+        m = 1 << 24
+        b = physics.plummer(m, seed=1)
+
+        def dist_ranks(nranks, mine):
+            per = (m + nranks - 1) // nranks
+            out = []
+            for r in mine:
+                dr = DistRank(r, nranks, device=local, precision="f32", theta=0.5)
+                dr.upload(int(per * 1.25) + 4096, b.pos[r * per:(r + 1) * per], b.vel[r * per:(r + 1) * per], b.mass[r * per:(r + 1) * per], r * per)
+                dr.use_torch_stream()
+                out.append(dr)
+            return out
+        ranks = dist_ranks(world, [rank])
+        tree = DistributedTree(ranks, TorchComm())
+        tree.distribute()
+        sec = timed_steps(lambda: tree.step(1), sync, barrier, 2, 5)      # (the first step moves every body to its owner)
+        acc = {}
+        for _ in range(3):
+            for k, v in tree.step_profiled().items():
+                acc[k] = acc.get(k, 0.0) + v / 3
+        live = float(ranks[0].engine.stats().n_alive)
+        if world > 1:
+            t = torch.tensor([sec] + [acc[k] for k in sorted(acc)], device="cuda", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            sec = float(t[0].item())
+            acc = {k: float(v) for k, v in zip(sorted(acc), t[1:].tolist())}
+            t = torch.tensor([live, -live], device="cuda", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            live = [float(t[0].item()), -float(t[1].item())]
+        extra["bh_theta0.5_fp32_plummer_16M_distributed_tree"] = {
+            "steps_per_s": 5 / sec, "ms_per_step": 1e3 * sec / 5, "phase_ms_max_over_ranks": acc,
+            "bodies_per_rank_max_min": live, "imported_nodes_this_rank": tree.last_import_nodes[0],
+            "migrated_bodies_this_rank": tree.last_migrated[0]}
+        for r in ranks:
+            r.close()
+
+    def emit():
+        if rank == 0:
+            os.write(json_fd, (json.dumps(line()) + "\n").encode())
+
+    if (world > 1 or force_dist) and not args.no_extra:
+        import threading
+        finished = threading.Event()
+
+        def watchdog():
+            if not finished.wait(float(os.environ.get("NBODY_BENCH_DIST_TIMEOUT", "300"))):
+                extra["bh_theta0.5_fp32_plummer_16M_distributed_tree"] = {"error": "did not finish in time; the rest of the line is complete"}
+                emit()
+                os._exit(0)
+        threading.Thread(target=watchdog, daemon=True).start()
+        try:
+            distributed_tree_extra()
+        except Exception as ex:
+            extra["bh_theta0.5_fp32_plummer_16M_distributed_tree"] = {"error": repr(ex)}
+            log("distributed tree extra failed:", ex)
+        finished.set()
+
+    def line():
+        return {"metric": "body-body interactions/sec", "value": value, "unit": "interactions/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * sec / args.steps, "steps_per_s": args.steps / sec,
                "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": workload, "bodies": n, "ic": "Plummer sphere a=2e3 m, M=1e9 kg, seed 1",
                           "dt": 3600.0, "eps": 0.0, "parallelism": f"targets sharded over {world} GPU(s), all-gather of pos+vel per step" if world > 1 else "single GPU"},
                "roofline": roofline, "cpu_baseline": cpu, "extra": extra}
-        os.write(json_fd, (json.dumps(out) + "\n").encode())
+
+    emit()
     if world > 1 or force_dist:
+        # a rank that failed above while the others were inside a collective would wait here for ever
+        import threading
+        threading.Timer(120.0, lambda: os._exit(0)).start()
         dist.barrier()
         dist.destroy_process_group()
+        os._exit(0)
 
 
 if __name__ == "__main__":
