@@ -146,6 +146,11 @@ __device__ __forceinline__ bool node_opens(const RawD& nd, double r2, double the
 // drain, was measured (the timing itself is free): 2.44 ms against 2.20 ms per step at 1M bodies, 4.62 against 4.14 at
 // 2M, 45.1 against 36.0 at 16M.  Workgroups that are neighbours in Morton order and run at the same time share their
 // near-field nodes in the XCD's L2 and the scalar cache; any other order costs more than the drain.
+// Cells with nothing but bodies below them hold a quarter of the visits, and a body's record can never open: taking such
+// a cell's bodies in a loop of their own (12 vector instructions each instead of 17: no test, no vote, no sit-out update;
+// the cursor passes over the subtree, the descend target stored in the record so that the request for the next node
+// stays one select away) gave the same bits at 2.14 ms against 1.89 ms (2.43 ms with the compiler's own loads, which it
+// turns into vector loads): the loop's records are waited for where the visit's are requested a whole visit ahead.
 template <typename R, typename A, typename NodeT, int OUT, bool COUNT, bool SOFT>
 __global__ __launch_bounds__(WALK_BLOCK) void walk_kernel(
     const NodeT* __restrict__ nodes, const int* __restrict__ counters, const typename V4<R>::type* __restrict__ posm,
