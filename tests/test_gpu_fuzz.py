@@ -106,3 +106,31 @@ def test_random_scenes_on_several_shards_equal_one_shard(gpu, block):
         elif len(out[0][0]):
             scale = np.abs(out[0][0]).max() + 1e-30
             assert np.abs(out[0][0] - out[1][0]).max() <= 1e-5 * scale, tag
+
+
+@pytest.mark.parametrize("block", range(2))
+def test_random_scenes_on_the_distributed_tree_equal_one_engine(gpu, block):
+    """The key-range-distributed tree behind one handle (2..6 shards on this GPU, every body on one shard only) on the
+    same random scenes, bodies on cell boundaries, outside the bound and NaN included: fp32 and fp64 bit for bit against
+    one engine that sums its cells child by child, mixed precision to rounding."""
+    for s in range(9500 + 10 * block, 9500 + 10 * (block + 1)):
+        rng = np.random.default_rng(s)
+        kind, pos, vel, mass, rad = scene(rng)
+        n = len(mass)
+        precision = str(rng.choice(["f32", "mixed", "f64"]))
+        shards = int(rng.integers(2, 7)); nsteps = int(rng.choice([1, 3, 6]))
+        theta = float(rng.choice([0.3, 0.6, 1.0]))
+        tag = f"seed {s}: {kind} n={n} {precision} shards={shards} steps={nsteps} theta={theta}"
+        out = []
+        for kw in (dict(tree_sums=True), dict(devices=[0] * shards, distributed=True)):
+            with Engine(mode="tree", precision=precision, theta=theta, dt=200.0, **kw) as e:
+                e.upload(pos, vel, mass)
+                e.step(nsteps)
+                out.append(e.download() + (e.stats().n_alive,))
+        assert out[0][4] == out[1][4], tag
+        assert np.array_equal(out[0][3], out[1][3]), tag
+        if precision == "mixed":
+            if len(out[0][0]):
+                assert np.abs(out[0][0] - out[1][0]).max() <= 1e-9 * (np.abs(out[0][0]).max() + 1e-30), tag
+        else:
+            assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1]), tag
