@@ -232,9 +232,10 @@ int nbe_device_state(nbe_engine *e, nbe_device_state_t *out);
  *     every body visits exactly the nodes it visits in the one-engine tree, in the same order, so fp32 and fp64 runs
  *     equal a one-engine run with cell_sums = NBE_SUMS_TREE bit for bit (NBE_PREC_MIXED to rounding: its partial sums
  *     are flushed by wavefront, and the wavefronts hold other bodies).
- *     (Bodies that share all 63 key bits, i.e. lie in the same 3 cm cell of the reference's bound, are kept in the order
- *     in which they reached their rank, where one engine keeps them in the order of its previous sort: the same
- *     interactions, summed in another order, so results then agree to rounding instead of bit for bit.)
+ *     (Bodies that share all 63 key bits, i.e. lie in the same 3 cm cell of the reference's bound, are ordered by their
+ *     upload index on one engine and by their run-wide index here, in runs of up to 64 such bodies, so they too are
+ *     summed in one order everywhere; a longer run keeps the order in which its bodies reached the rank, and results
+ *     then agree to rounding instead of bit for bit.)
  * Tree mode, collisions off, NBE_WALK_PER_BODY, no reference_quirks.  nbe_step and the nbe_shard_* calls are refused on
  * such an engine. */
 typedef struct {

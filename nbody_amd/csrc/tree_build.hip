@@ -455,8 +455,16 @@ __device__ __forceinline__ unsigned xcd_contiguous_block(void)
 }
 
 // Reorders the state into sorted order (gather): dst[i] = src[idx[i]].
+// Bodies with the same key (coincident, or in the same depth-21 cell) come out of the stable sort in the order of the
+// previous sort, which depends on the run's history and, on the distributed tree, on when a body reached its rank.  They
+// are put in the order of their upload (run-wide) indices instead, so that their order, and with it the order in which
+// their forces are summed, is a property of the scene: a member of a run of up to TIE_MAX equal keys counts the members
+// with smaller indices and goes to that place of the run (every member sees the whole run and they all decide alike;
+// longer runs keep the sort's order).
+#define TIE_MAX 64
 template <typename S4>
-__global__ __launch_bounds__(256) void permute_kernel(const uint32_t* __restrict__ idx, int n, const S4* __restrict__ pos_in,
+__global__ __launch_bounds__(256) void permute_kernel(const uint32_t* __restrict__ idx, const uint64_t* __restrict__ keys, int n,
+                                                      const S4* __restrict__ pos_in,
                                                       const S4* __restrict__ vel_in, const uint32_t* __restrict__ orig_in,
                                                       const float4* __restrict__ mirror_in, const double* __restrict__ radius_in,
                                                       S4* __restrict__ pos_out, S4* __restrict__ vel_out,
@@ -476,11 +484,25 @@ __global__ __launch_bounds__(256) void permute_kernel(const uint32_t* __restrict
     if (i >= n) return;
     // (four bodies per thread with all gathers in flight together: 590 against 514 us at 16M bodies)
     const uint32_t j = idx[i];
-    pos_out[i] = pos_in[j];
-    vel_out[i] = vel_in[j];
-    orig_out[i] = orig_in[j];
-    if (mirror_in) mirror_out[i] = mirror_in[j];
-    if (radius_in) radius_out[i] = radius_in[j];
+    int to = i;
+    const uint64_t key = keys[i];
+    if (key != KEY_DEAD && ((i > 0 && keys[i - 1] == key) || (i + 1 < n && keys[i + 1] == key))) {
+        int a = i, b = i;                             // the run [a, b] of this key, as far as TIE_MAX steps show it
+        while (a > 0 && i - a < TIE_MAX && keys[a - 1] == key) a--;
+        while (b + 1 < n && b - i < TIE_MAX && keys[b + 1] == key) b++;
+        const bool whole = (a == 0 || keys[a - 1] != key) && (b + 1 >= n || keys[b + 1] != key);
+        if (whole && b - a < TIE_MAX) {
+            const uint32_t mine = orig_in[j];
+            int before = 0;
+            for (int t = a; t <= b; t++) before += orig_in[idx[t]] < mine ? 1 : 0;
+            to = a + before;
+        }
+    }
+    pos_out[to] = pos_in[j];
+    vel_out[to] = vel_in[j];
+    orig_out[to] = orig_in[j];
+    if (mirror_in) mirror_out[to] = mirror_in[j];
+    if (radius_in) radius_out[to] = radius_in[j];
 }
 
 // ---- binary radix tree over the sorted keys ----------------------------------------------------------------
@@ -1114,7 +1136,7 @@ static int sort_and_build_t(nbe_engine* e)
     if (!e->keys_sorted) NBE_TRY(sort_keys_t<R4>(e));        // unless tree_sort_keys ran ahead of this call
     e->keys_sorted = false;
     NBE_TRY(frame_stream_guard_write(e, nxt));
-    hipLaunchKernelGGL((permute_kernel<S4>), dim3(cdiv((size_t)n + 1, 256)), dim3(256), 0, e->stream, w.sidx[0], n, (const S4*)e->posm[cur],
+    hipLaunchKernelGGL((permute_kernel<S4>), dim3(cdiv((size_t)n + 1, 256)), dim3(256), 0, e->stream, w.sidx[0], w.keys[0], n, (const S4*)e->posm[cur],
                        (const S4*)e->vel[cur], e->orig[e->orig_cur], mixed ? e->mirror[cur] : (const float4*)nullptr,
                        (const double*)e->radius[cur], (S4*)e->posm[nxt], (S4*)e->vel[nxt], e->orig[e->orig_cur ^ 1],
                        mixed ? e->mirror[nxt] : (float4*)nullptr, e->radius[nxt], w.counters, w.lvlmask);
