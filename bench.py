@@ -98,6 +98,37 @@ def cpu_baseline_tree(n, theta):
             "sample": f"one force pass on {n} bodies, theta={theta}, serial build + 4 walk threads"}
 
 
+def eight_ranks_on_one_gpu(b, one_gpu_ms, **engine_kw):
+    """A scene on the key-range-distributed tree with eight ranks side by side on the current GPU, phases drained one by
+    one: a rank's share of the sums is what one GPU of an eight-GPU run does per step (the exchanges are device copies
+    here).  Medians over five steps, so that one stalled phase does not colour the table."""
+    import torch
+    from nbody_amd.disttree import DistRank, DistributedTree, LocalComm
+    nr = 8
+    m = len(b.mass)
+    per = (m + nr - 1) // nr
+    ranks = []
+    try:
+        for r in range(nr):
+            dr = DistRank(r, nr, device=torch.cuda.current_device(), **engine_kw)
+            ranks.append(dr)
+            dr.upload(int(per * 1.25) + 4096, b.pos[r * per:(r + 1) * per], b.vel[r * per:(r + 1) * per], b.mass[r * per:(r + 1) * per], r * per)
+            dr.use_torch_stream()
+        tree = DistributedTree(ranks, LocalComm(nr))
+        tree.distribute()
+        tree.step(2)                    # (the first step moves every body to its owner)
+        runs = [tree.step_profiled() for _ in range(5)]
+        acc = {k: float(np.median([t[k] for t in runs])) for k in runs[0]}
+        per_rank = {k: v / nr for k, v in acc.items()}
+        return {"phase_ms_sum_over_ranks": acc, "phase_ms_per_rank": per_rank, "ms_per_step_per_rank": sum(per_rank.values()),
+                "one_gpu_ms_per_step": one_gpu_ms, "ratio_one_gpu_step_to_rank_step": one_gpu_ms / sum(per_rank.values()),
+                "imported_nodes_per_rank": tree.last_import_nodes, "migrated_bodies_per_rank": tree.last_migrated,
+                "bodies_per_rank": [int(r.engine.stats().n_alive) for r in ranks], "rebalances": tree.rebalances}
+    finally:
+        for r in ranks:
+            r.close()
+
+
 def main():
     args = parse()
     # Libraries (RCCL prints a version banner) write to file descriptor 1; keep the real stdout for the one JSON
@@ -258,43 +289,12 @@ def main():
         e3.close()
         # The same cloud and the same per-body walk with the key-range-distributed tree (nbe_dist_*): every body resident
         # on one GPU, every GPU sorts and builds its own N/G bodies, pruned subtrees are exchanged.
-        from nbody_amd.disttree import DistRank, DistributedTree, LocalComm, TorchComm
-        b = physics.plummer(m, seed=1)
-
-        def dist_ranks(nranks, mine):
-            per = (m + nranks - 1) // nranks
-            out = []
-            for r in mine:
-                dr = DistRank(r, nranks, device=local, precision="f32", theta=0.5)
-                dr.upload(int(per * 1.25) + 4096, b.pos[r * per:(r + 1) * per], b.vel[r * per:(r + 1) * per], b.mass[r * per:(r + 1) * per], r * per)
-                dr.use_torch_stream()
-                out.append(dr)
-            return out
-
-        if world > 1 or force_dist:
-            pass        # (one rank per GPU: measured last, under a watchdog, see distributed_tree_extra below)
-        else:
-            # one GPU: eight ranks side by side on it, phases drained one by one; a rank's share of the sums is what a GPU
-            # of an eight-GPU run does per step (the exchanges are device copies here)
-            nr = 8
-            ranks = dist_ranks(nr, range(nr))
-            tree = DistributedTree(ranks, LocalComm(nr))
-            tree.distribute()
-            tree.step(2)
-            acc = {}
-            for _ in range(3):
-                for k, v in tree.step_profiled().items():
-                    acc[k] = acc.get(k, 0.0) + v / 3
-            per_rank = {k: v / nr for k, v in acc.items()}
-            one = extra["bh_theta0.5_fp32_plummer_16M"]["ms_per_step"]
-            extra["bh_theta0.5_fp32_plummer_16M_distributed_tree_8_ranks_on_one_gpu"] = {
-                "phase_ms_sum_over_ranks": acc, "phase_ms_per_rank": per_rank, "ms_per_step_per_rank": sum(per_rank.values()),
-                "one_gpu_ms_per_step": one, "ratio_one_gpu_step_to_rank_step": one / sum(per_rank.values()),
-                "imported_nodes_per_rank": tree.last_import_nodes, "migrated_bodies_per_rank": tree.last_migrated,
-                "bodies_per_rank": [int(r.engine.stats().n_alive) for r in ranks]}
-            for r in ranks:
-                r.close()
-        del b
+        # (one rank per GPU: measured last, under a watchdog, see distributed_tree_extra below)
+        if world == 1 and not force_dist:
+            b = physics.plummer(m, seed=1)
+            extra["bh_theta0.5_fp32_plummer_16M_distributed_tree_8_ranks_on_one_gpu"] = eight_ranks_on_one_gpu(
+                b, extra["bh_theta0.5_fp32_plummer_16M"]["ms_per_step"], precision="f32", theta=0.5)
+            del b
         # the same cloud with the opening test taken per wavefront of 128 bodies (finer than the reference's per-body
         # test, not its interaction set; off by default), also on every GPU count
         e3w, s3w = run("tree", m, "f32", 0.5, 5, 1, per_wave=True)
@@ -397,6 +397,11 @@ def main():
                             "|dP|/sum m|v| <= 1e-5 after 100, <= 1e-3 after 1000",
             "note": "potential summed over the nodes the walk accepts (theta 0.5) at every checkpoint"}
         e6.close()
+        # the same scene on the key-range-distributed tree, eight ranks side by side on this GPU
+        gp = physics.galaxy_pair(1 << 23, seed=1)
+        extra["galaxy_pair_2x8M_bh_mixed_eps1_distributed_tree_8_ranks_on_one_gpu"] = eight_ranks_on_one_gpu(
+            gp, extra["galaxy_pair_2x8M_bh_mixed_eps1"]["ms_per_step"], precision="mixed", theta=0.5, eps=1.0)
+        del gp
         # the reference's own precision (fp64 throughout) and the mixed mode on the headline cloud: direct-sum force
         # kernel and Barnes-Hut step, each with its fraction of the vector peak of its arithmetic
         pd = physics.plummer(1 << 20, seed=1)
@@ -477,10 +482,8 @@ def main():
         tree = DistributedTree(ranks, TorchComm())
         tree.distribute()
         sec = timed_steps(lambda: tree.step(1), sync, barrier, 2, 5)      # (the first step moves every body to its owner)
-        acc = {}
-        for _ in range(3):
-            for k, v in tree.step_profiled().items():
-                acc[k] = acc.get(k, 0.0) + v / 3
+        runs = [tree.step_profiled() for _ in range(5)]
+        acc = {k: float(np.median([t[k] for t in runs])) for k in runs[0]}
         live = float(ranks[0].engine.stats().n_alive)
         if world > 1:
             t = torch.tensor([sec] + [acc[k] for k in sorted(acc)], device="cuda", dtype=torch.float64)
