@@ -82,7 +82,9 @@ struct DistState {
     size_t export_cap = 0;
     unsigned long long* d_export_base = nullptr;   // [0, world] first exported node per destination and the end; then two batch bases
     int* d_export_sizes = nullptr;      // world x NBE_DIST_MAX_FRAGMENTS
-    double* d_boxes = nullptr;          // world x MAX_BOXES x 6
+    int* d_frag_bodies = nullptr;       // [MAX_FRAGMENTS][2]: first body and one past the last body of every fragment
+    double* d_boxes = nullptr;          // world x (MAX_BOXES + 1) x 6: a rank's boxes, then the box around them all
+    std::vector<double> boxes_host;
     int* d_box_counts = nullptr;        // world
     // import + assembled array
     void* import_nodes = nullptr;
@@ -108,7 +110,7 @@ void dist_destroy(nbe_engine* e)
     void** dev[] = {(void**)&d->d_split, (void**)&d->d_counts, &d->outbox, &d->inbox, (void**)&d->free_slots, (void**)&d->d_frags,
                     (void**)&d->d_nfrag, (void**)&d->d_aabb, (void**)&d->x_diff, (void**)&d->x_cover, (void**)&d->x_flag,
                     (void**)&d->x_index, (void**)&d->d_seg_first, &d->export_nodes, (void**)&d->d_export_base, (void**)&d->d_export_sizes,
-                    (void**)&d->d_boxes, (void**)&d->d_box_counts, &d->import_nodes, &d->let_nodes, (void**)&d->let_counters, (void**)&d->d_segments,
+                    (void**)&d->d_boxes, (void**)&d->d_frag_bodies, (void**)&d->d_box_counts, &d->import_nodes, &d->let_nodes, (void**)&d->let_counters, (void**)&d->d_segments,
                     (void**)&d->d_top};
     for (void** p : dev) (void)dfree(p);
     void* host[] = {d->h_counts, d->h_frags, d->h_small, d->h_aabb, d->h_segments, d->h_seg_first, d->h_top, d->h_let_counters};
@@ -195,6 +197,7 @@ extern "C" int nbe_dist_upload(nbe_engine* e, int rank, int world, size_t capaci
     NBE_HIP(hipMalloc((void**)&d->d_nfrag, 2 * sizeof(int)));
     NBE_HIP(hipHostMalloc((void**)&d->h_frags, NBE_DIST_MAX_FRAGMENTS * sizeof(nbe_fragment_t), hipHostMallocDefault));
     NBE_HIP(hipHostMalloc((void**)&d->h_small, (16 + (W2 + 1) * 2 + W2 * NBE_DIST_MAX_FRAGMENTS) * sizeof(int), hipHostMallocDefault));
+    NBE_HIP(hipMalloc((void**)&d->d_frag_bodies, (size_t)NBE_DIST_MAX_FRAGMENTS * 2 * sizeof(int)));
     NBE_HIP(hipMalloc((void**)&d->d_aabb, (size_t)NBE_DIST_MAX_FRAGMENTS * (BOX_PARTS + 1) * 6 * sizeof(double)));
     NBE_HIP(hipHostMalloc((void**)&d->h_aabb, (size_t)NBE_DIST_MAX_FRAGMENTS * 6 * sizeof(double), hipHostMallocDefault));
     // export work arrays (see export_t): two packed words per node and their scan, a byte and a 64-bit word per node,
@@ -217,7 +220,7 @@ extern "C" int nbe_dist_upload(nbe_engine* e, int rank, int world, size_t capaci
     NBE_HIP(hipMemsetAsync(d->let_counters, 0, 16 * sizeof(int), e->stream));
     NBE_HIP(hipMalloc((void**)&d->d_export_base, (W2 + 3) * sizeof(unsigned long long)));
     NBE_HIP(hipMalloc((void**)&d->d_export_sizes, W2 * NBE_DIST_MAX_FRAGMENTS * sizeof(int)));
-    NBE_HIP(hipMalloc((void**)&d->d_boxes, W2 * NBE_DIST_MAX_BOXES * 6 * sizeof(double)));
+    NBE_HIP(hipMalloc((void**)&d->d_boxes, W2 * (NBE_DIST_MAX_BOXES + 1) * 6 * sizeof(double)));
     NBE_HIP(hipMalloc((void**)&d->d_box_counts, W2 * sizeof(int)));
     d->seg_cap = W2 * NBE_DIST_MAX_FRAGMENTS;
     d->top_cap = W2 * NBE_DIST_MAX_FRAGMENTS;
@@ -498,7 +501,8 @@ __device__ __forceinline__ bool cell_inside(uint64_t key, int level, uint64_t lo
 // A node roots a fragment iff its cell is inside the rank's key range and the cell of the node above is not.
 __global__ __launch_bounds__(256) void fragments_kernel(const CNode* __restrict__ cn, const int* __restrict__ counters,
                                                         const double* __restrict__ node_sum, uint64_t lo, uint64_t hi,
-                                                        nbe_fragment_t* __restrict__ frags, int* __restrict__ nfrag)
+                                                        nbe_fragment_t* __restrict__ frags, int* __restrict__ nfrag,
+                                                        int* __restrict__ frag_bodies)
 {
     const int total = counters[1];
     const int p = blockIdx.x * 256 + threadIdx.x;
@@ -517,31 +521,23 @@ __global__ __launch_bounds__(256) void fragments_kernel(const CNode* __restrict_
     f.reserved = at;                                  // its place in this (unordered) list: where its box will be
     for (int k = 0; k < 4; k++) f.sum[k] = node_sum[4 * (size_t)p + k];
     frags[at] = f;
+    // its bodies: in pre-order the first children of the cells below follow the root one by one down to the first leaf,
+    // and the last node of the subtree is its last leaf
+    int first = p;
+    while (cn[first].body < 0) first++;
+    frag_bodies[2 * at] = cn[first].body;
+    frag_bodies[2 * at + 1] = cn[c.skip - 1].body + 1;
 }
 
-// Box of the bodies of every fragment (its keys are the keys of its cell): BOX_PARTS workgroups share a fragment's bodies,
-// then one thread per fragment and coordinate reduces.  The grid covers the largest possible number of fragments.
+// Box of the bodies of every fragment: BOX_PARTS workgroups share a fragment's bodies, then one thread per fragment and
+// coordinate reduces.  The grid covers the largest possible number of fragments.
 template <typename R4>
-__global__ __launch_bounds__(256) void box_partial_kernel(const R4* __restrict__ pos, const uint64_t* __restrict__ keys,
-                                                          const int* __restrict__ counters, const nbe_fragment_t* __restrict__ frags,
+__global__ __launch_bounds__(256) void box_partial_kernel(const R4* __restrict__ pos, const int* __restrict__ frag_bodies,
                                                           const int* __restrict__ nfrag, double* __restrict__ part)
 {
-    const int na = counters[0];
     const int g = blockIdx.y;
     if (g >= *nfrag || g >= NBE_DIST_MAX_FRAGMENTS) return;
-    const nbe_fragment_t f = frags[g];
-    uint64_t kmin = f.key, kmax = f.key;
-    if (f.level < 21) {
-        const uint64_t size = 1ull << (3 * (21 - f.level));
-        kmin = f.key & ~(size - 1ull);
-        kmax = kmin + (size - 1ull);
-    }
-    int lo = 0, hi = na;                              // first body with key >= kmin
-    while (lo < hi) { const int mid = (lo + hi) >> 1; if (keys[mid] < kmin) lo = mid + 1; else hi = mid; }
-    const int first = lo;
-    hi = na;                                          // first body with key > kmax
-    while (lo < hi) { const int mid = (lo + hi) >> 1; if (keys[mid] <= kmax) lo = mid + 1; else hi = mid; }
-    const int last = lo;
+    const int first = frag_bodies[2 * g], last = frag_bodies[2 * g + 1];
     double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (int i = first + blockIdx.x * 256 + threadIdx.x; i < last; i += BOX_PARTS * 256) {
         const R4 p = pos[i];
@@ -620,10 +616,10 @@ static int fragment_boxes(nbe_engine* e, int rows)
     double* part = d->d_aabb + (size_t)NBE_DIST_MAX_FRAGMENTS * 6;
     if (e->cfg.precision == NBE_PREC_F64)
         hipLaunchKernelGGL((box_partial_kernel<double4>), dim3(BOX_PARTS, rows), dim3(256), 0, e->stream, (const double4*)key_positions(e),
-                           e->tw.keys[0], e->tw.counters, d->d_frags, d->d_nfrag, part);
+                           d->d_frag_bodies, d->d_nfrag, part);
     else
         hipLaunchKernelGGL((box_partial_kernel<float4>), dim3(BOX_PARTS, rows), dim3(256), 0, e->stream, (const float4*)key_positions(e),
-                           e->tw.keys[0], e->tw.counters, d->d_frags, d->d_nfrag, part);
+                           d->d_frag_bodies, d->d_nfrag, part);
     hipLaunchKernelGGL(box_final_kernel, dim3(cdiv((size_t)rows * 6, 256)), dim3(256), 0, e->stream, part, d->d_nfrag, d->d_aabb);
     NBE_HIP(hipGetLastError());
     NBE_HIP(hipMemcpyAsync(d->h_aabb, d->d_aabb, (size_t)rows * 6 * sizeof(double), hipMemcpyDeviceToHost, e->stream));
@@ -649,7 +645,7 @@ extern "C" int nbe_dist_build(nbe_engine* e, nbe_fragment_t* frags, int max, int
         NBE_TRY(tree_sort_and_build(e));
         NBE_TRY(collide_emit_geometry(e));
         hipLaunchKernelGGL(fragments_kernel, dim3(cdiv(2 * e->n, 256)), dim3(256), 0, e->stream, e->cw.cnodes, e->tw.counters,
-                           e->tw.node_sum, d->split[d->rank], d->split[d->rank + 1], d->d_frags, d->d_nfrag);
+                           e->tw.node_sum, d->split[d->rank], d->split[d->rank + 1], d->d_frags, d->d_nfrag, d->d_frag_bodies);
         NBE_TRY(fragment_boxes(e, box_rows));
     }
     NBE_HIP(hipGetLastError());
@@ -719,9 +715,12 @@ __device__ __forceinline__ double open_reach2(const NodeD& nd, double theta, dou
     const double t = nd.w * sqrt((1.0 + rel) / (1.0 - rel)) / theta + slack;      // opens iff w / r > theta
     return t * t;
 }
+// (boxes: the rank's nboxes boxes, and at index NBE_DIST_MAX_BOXES the box around all of them: most cells are far from a
+// rank and one test against that box settles them)
 template <typename NodeT>
 __device__ __forceinline__ bool may_open(const NodeT& nd, double reach2, const double* __restrict__ boxes, int nboxes)
 {
+    if (nboxes == 0 || !(box_distance2((double)nd.x, (double)nd.y, (double)nd.z, boxes + 6 * NBE_DIST_MAX_BOXES) < reach2)) return false;
     for (int b = 0; b < nboxes; b++)
         if (box_distance2((double)nd.x, (double)nd.y, (double)nd.z, boxes + 6 * b) < reach2) return true;
     return false;
@@ -752,7 +751,7 @@ __global__ __launch_bounds__(256) void export_mark_kernel(const NodeT* __restric
     uint32_t add[2] = {0u, 0u};
     for (int j = 0; j < dests.n; j++) {
         const int q = dests.q[j];
-        if (!may_open(nd, reach2, boxes + 6 * (size_t)NBE_DIST_MAX_BOXES * q, nboxes[q])) add[j >> 2] += 1u << (8 * (j & 3));
+        if (!may_open(nd, reach2, boxes + 6 * (size_t)(NBE_DIST_MAX_BOXES + 1) * q, nboxes[q])) add[j >> 2] += 1u << (8 * (j & 3));
     }
 #pragma unroll
     for (int h = 0; h < 2; h++)
@@ -955,7 +954,21 @@ extern "C" int nbe_dist_export(nbe_engine* e, const nbe_fragment_t* all_frags, c
     if (total > 0 && !all_frags) { nbe_set_error("all_frags is NULL"); return NBE_E_INVALID; }
     d->all_frags.assign(all_frags, all_frags + total);
     d->frag_counts.assign(frag_counts, frag_counts + d->world);
-    NBE_HIP(hipMemcpyAsync(d->d_boxes, boxes, (size_t)d->world * NBE_DIST_MAX_BOXES * 6 * sizeof(double), hipMemcpyHostToDevice, e->stream));
+    d->boxes_host.assign((size_t)d->world * (NBE_DIST_MAX_BOXES + 1) * 6, 0.0);
+    for (int r = 0; r < d->world; r++) {
+        const double* src = boxes + (size_t)r * NBE_DIST_MAX_BOXES * 6;
+        double* dst = d->boxes_host.data() + (size_t)r * (NBE_DIST_MAX_BOXES + 1) * 6;
+        double* all = dst + (size_t)NBE_DIST_MAX_BOXES * 6;
+        for (int c = 0; c < 3; c++) { all[c] = INFINITY; all[3 + c] = -INFINITY; }
+        for (int b = 0; b < box_counts[r]; b++)
+            for (int c = 0; c < 3; c++) {
+                dst[6 * b + c] = src[6 * b + c];
+                dst[6 * b + 3 + c] = src[6 * b + 3 + c];
+                all[c] = fmin(all[c], src[6 * b + c]);
+                all[3 + c] = fmax(all[3 + c], src[6 * b + 3 + c]);
+            }
+    }
+    NBE_HIP(hipMemcpyAsync(d->d_boxes, d->boxes_host.data(), d->boxes_host.size() * sizeof(double), hipMemcpyHostToDevice, e->stream));
     NBE_HIP(hipMemcpyAsync(d->d_box_counts, box_counts, (size_t)d->world * sizeof(int), hipMemcpyHostToDevice, e->stream));
     int rc = e->force64 ? export_t<NodeD>(e, export_sizes, export_offsets) : export_t<NodeF>(e, export_sizes, export_offsets);
     if (rc == NBE_OK) d->exported = true;
