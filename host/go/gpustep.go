@@ -22,7 +22,7 @@ var (
 	gpuPerWave   = flag.Bool("perwave", false, "tree mode: the bodies of a wavefront open cells together (not the reference's interaction set)")
 	gpuCount     = flag.Int("gpus", 1, "GPUs driven by the one engine (with collisions on: -tree only)")
 	gpuBlocking  = flag.Bool("blockingframes", false, "take frames with a blocking download instead of the side-stream ring")
-	gpuDist      = flag.Bool("distributed", false, "with -gpus N -tree -nocollision: every body on one GPU only, pruned subtrees exchanged; frames by blocking download")
+	gpuDist      = flag.Bool("distributed", false, "with -gpus N -tree -nocollision: every body on one GPU only, pruned subtrees exchanged")
 )
 
 func gpuOptionsFromFlags() gpuOptions {
@@ -51,7 +51,7 @@ func gpuRun(bodies []*body, tree, nocollision, norender bool, theta float64, dt 
 	// Frames leave the GPU on a side stream into a ring of pinned buffers while the next step computes, and the
 	// engine's delivery thread sends them on ch (framestream.go); -blockingframes keeps the synchronous copy.
 	var fs *frameStream
-	if !norender && !*gpuBlocking && !*gpuDist { // (the distributed tree has no frame stream: frames come from nbe_download)
+	if !norender && !*gpuBlocking {
 		fs = eng.streamFrames(iterPerFrame, cap(ch), startFrame, ch)
 	}
 	start := time.Now()

@@ -4,7 +4,7 @@
 // reference's flags, its body type, its initial-condition generator and its frame loop:
 //   flags           main.go:17-24   -n -y -state -save -tree -norender -nocollision
 //                   (+ -seed -frames-dir -precision -asgo -perwave, and the reference's compile-time constants as
-//                   run-time values: -gpus N (one engine, N GPUs), -theta main.go:73, -dt main.go:28, -bound main.go:74-76, -eps softening, -G physics.go:132)
+//                   run-time values: -gpus N (one engine, N GPUs; -devices 0,0,1 names them, an ordinal may repeat), -theta main.go:73, -dt main.go:28, -bound main.go:74-76, -eps softening, -G physics.go:132)
 //   makebodies      physics.go:16-73 with the two cores of main.go:35-36
 //   frame loop      main.go:80-190  (frames+1 iterations; a frame copy goes to the workers BEFORE each step)
 //   output workers  main.go:50-61   4 consumers behind a queue of capacity 32 (here fed by nbe_frame_stream_begin)
@@ -250,6 +250,7 @@ int main(int argc, char** argv)
     double eps = 0, bound = 65536, gconst = G;               // no softening; simbound main.go:74-76; physics.go:132
     int precision = NBE_PREC_F32;
     int gpus = 1;                                            // the walk's fan-out (main.go:134-149) over this many GPUs
+    std::vector<int> devices;                                // -devices: their ordinals (default 0 .. gpus-1)
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
         if (a.rfind("--", 0) == 0) a = a.substr(1);
@@ -266,6 +267,16 @@ int main(int argc, char** argv)
         else if (const char* v = val("-theta")) theta = std::atof(v);
         else if (const char* v = val("-dt")) dt = std::atof(v);
         else if (const char* v = val("-gpus")) gpus = std::atoi(v);
+        else if (const char* v = val("-devices")) {
+            devices.clear();
+            for (const char* p = v; *p;) {
+                char* end = nullptr;
+                devices.push_back((int)std::strtol(p, &end, 10));
+                if (end == p) panic(std::string("-devices: not a list of ordinals: ") + v);
+                p = *end == ',' ? end + 1 : end;
+            }
+            gpus = (int)devices.size();
+        }
         else if (const char* v = val("-eps")) eps = std::atof(v);
         else if (const char* v = val("-bound")) bound = std::atof(v);
         else if (const char* v = val("-G")) gconst = std::atof(v);
@@ -324,8 +335,8 @@ int main(int argc, char** argv)
     cfg.precision = precision;
     cfg.collisions = nocollision ? 0 : 1;                    // main.go:24
     cfg.num_devices = gpus;                                  // > 1: devices 0 .. gpus-1 (with collisions on: -tree only)
-    // -distributed (with -gpus N -tree -nocollision -norender): every body on one GPU only, pruned subtrees exchanged;
-    // frames are then taken with nbe_download instead of the frame stream
+    if (!devices.empty()) cfg.device_ids = devices.data();
+    // -distributed (with -gpus N -tree -nocollision): every body on one GPU only, pruned subtrees exchanged
     cfg.distributed = distributed ? 1 : 0;
     // -asgo: the tree path with the Go program's own arithmetic (running cell centres tree.go:189-193, last
     // n mod 4 bodies unwalked main.go:134-148), for comparing a run with the reference number for number
@@ -356,10 +367,6 @@ int main(int argc, char** argv)
     ctx.ch = &ch;
     ctx.radius_by_id = &radius_by_id;
     ctx.remaining = (int)n;
-    if (distributed && !norender) {
-        std::fprintf(stderr, "-distributed keeps no GPU with all bodies, so there is no frame stream: run with -norender (and -save for the final state)\n");
-        return 2;
-    }
     if (!norender) check(nbe_frame_stream_begin(eng, iterPerFrame, 32, startFrame, on_frame, &ctx));
 
     const auto start = std::chrono::steady_clock::now();

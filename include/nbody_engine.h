@@ -72,9 +72,10 @@ typedef struct {
  * nbe_device_state and the nbe_shard_* calls are refused with NBE_E_UNSUPPORTED.  The same ordinal may be listed more than once (several shards on one GPU).
  * With cfg.distributed = 1 (tree mode, collisions off, per-body criterion, no reference_quirks) the GPUs do not replicate the
  * bodies: the engine runs the key-range-distributed tree described at nbe_dist_upload below on its GPUs, one host thread per
- * GPU, with peer copies for the exchanges.  nbe_upload, nbe_step, nbe_download, nbe_stats, nbe_energy (tree potential) and
- * nbe_sync work; results equal those of one GPU with cell_sums = NBE_SUMS_TREE bit for bit in fp32 and fp64; the other
- * calls are refused. */
+ * GPU, with peer copies for the exchanges.  nbe_upload, nbe_step, nbe_download, nbe_stats, nbe_energy (tree potential),
+ * nbe_sync and the frame stream work (no GPU holds all bodies: every GPU snapshots its own before the step and sends
+ * them into its stretch of the frame's pinned buffer on a stream of its own; the rows of a frame are in key order);
+ * results equal those of one GPU with cell_sums = NBE_SUMS_TREE bit for bit in fp32 and fp64; the other calls are refused. */
 
 /* How a cell's mass and centre of mass are summed (fp64 either way).
  *   NBE_SUMS_PREFIX   differences of prefix sums over the Morton-sorted bodies: three launches, the fastest, and the

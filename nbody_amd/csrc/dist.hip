@@ -487,6 +487,8 @@ extern "C" int nbe_dist_receive(nbe_engine* e, size_t k)
     return NBE_OK;
 }
 
+size_t dist_live_slots(const nbe_engine* e) { return e->dist ? e->dist->live_hi : 0; }
+
 // ---- build: local tree, fragments, bounding box ---------------------------------------------------------------------
 // Is the depth-`level` cell around `key` wholly inside [lo, hi)?  (A body, level 255, always is: it is here because its
 // key is.)

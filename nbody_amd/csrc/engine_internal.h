@@ -207,6 +207,9 @@ bool multi_is_distributed(const nbe_engine* e);  // cfg.distributed: no GPU hold
 int multi_dist_download(nbe_engine* e, double* pos, double* vel, double* mass, uint64_t* id, size_t* n_alive_out);
 int multi_dist_energy(nbe_engine* e, double* ke, double* pe, double mom[3]);
 int multi_dist_stats(nbe_engine* e, nbe_stats_t* out);
+int multi_dist_frames_begin(nbe_engine* e, int every, int slots, int first_frame, nbe_frame_cb cb, void* user);
+int multi_dist_frames_end(nbe_engine* e);
+size_t dist_live_slots(const nbe_engine* e);    // a rank's slots [0, this) may hold bodies; all of them do between a build and the next classify
 // dist.hip
 void dist_destroy(nbe_engine* e);
 // engine.hip

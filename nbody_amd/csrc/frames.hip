@@ -131,7 +131,7 @@ static int frame_stream_allocate(nbe_engine* e, int slots)
 extern "C" int nbe_frame_stream_begin(nbe_engine* e, int every, int slots, int first_frame, nbe_frame_cb cb, void* user)
 {
     if (!e || !cb) { nbe_set_error("nbe_frame_stream_begin: NULL argument"); return NBE_E_INVALID; }
-    if (multi_is_distributed(e)) { nbe_set_error("nbe_frame_stream_begin is not available on an engine with distributed = 1 (no GPU holds all bodies; use nbe_download)"); return NBE_E_UNSUPPORTED; }
+    if (multi_is_distributed(e)) return multi_dist_frames_begin(e, every, slots, first_frame, cb, user);      // every GPU sends its own bodies
     if (e->multi) e = multi_first(e);          // several GPUs: every one holds the full state; the first one streams it
     if (every < 1 || slots < 1 || slots > 1024) { nbe_set_error("every must be >= 1 and slots in 1..1024"); return NBE_E_INVALID; }
     if (e->fs.active) { nbe_set_error("frame streaming is already on"); return NBE_E_INVALID; }
@@ -252,6 +252,7 @@ int frame_stream_stop(nbe_engine* e)
 extern "C" int nbe_frame_stream_end(nbe_engine* e)
 {
     if (!e) { nbe_set_error("engine is NULL"); return NBE_E_INVALID; }
+    if (multi_is_distributed(e)) return multi_dist_frames_end(e);
     if (e->multi) e = multi_first(e);
     return frame_stream_stop(e);
 }

@@ -80,8 +80,43 @@ struct Workers {
 };
 
 // State of the distributed tree behind one handle (cfg.distributed): what disttree.py keeps per step, for all GPUs.
+// Frames of a distributed run (main.go:90-101): no GPU holds all bodies, so every GPU sends its own, in rank order, into
+// one pinned buffer; a delivery thread hands the whole frame to the host's callback.
+struct DistFrameSlot {
+    float* xyzm = nullptr;             // pinned, n_total x 4 floats
+    uint32_t* orig = nullptr;          // pinned, n_total upload indices
+    std::vector<hipEvent_t> done;      // per GPU: its part has landed
+    size_t n = 0;
+    int frame = 0;
+    bool busy = false;
+};
+
+struct DistFrames {
+    bool active = false;
+    int every = 1, first_frame = 0;
+    uint64_t step_base = 0, last_k = 0;
+    bool have_last = false;
+    nbe_frame_cb cb = nullptr;
+    void* user = nullptr;
+    // per GPU: a snapshot of its bodies taken on its compute stream (the step that follows parks and overwrites them),
+    // sent to the host on a stream of its own while the step computes
+    std::vector<hipStream_t> side;
+    std::vector<float4*> snap_xyzm;
+    std::vector<uint32_t*> snap_orig;
+    std::vector<hipEvent_t> snapped, sent;
+    std::vector<char> sending;
+    std::vector<DistFrameSlot> slots;
+    std::deque<int> queue;
+    std::mutex mu;
+    std::condition_variable cv_work, cv_free;
+    std::thread worker;
+    bool stop = false;
+    std::vector<uint64_t> ids_scratch;
+};
+
 struct DistMulti {
     Workers pool;
+    DistFrames frames;
     size_t n_total = 0;
     std::vector<uint64_t> ids;                       // upload order
     std::vector<size_t> capacity;
@@ -130,6 +165,7 @@ void multi_destroy(nbe_engine* e)
 {
     MultiState* m = e->multi;
     if (m) {
+        if (m->dist) (void)multi_dist_frames_end(e);
         for (size_t r = 0; r < m->subs.size(); r++) {
             if (m->subs[r]) (void)nbe_sync(m->subs[r]);
         }
@@ -269,6 +305,7 @@ static int dist_upload(nbe_engine* e, size_t n, const double* pos, const double*
     DistMulti* d = m->dist;
     const size_t G = m->subs.size();
     const size_t per = (n + G - 1) / G;
+    NBE_TRY(multi_dist_frames_end(e));               // (as an upload ends the frame stream of one engine)
     e->n = 0;
     d->prepared = false; d->want_rebalance = false;
     d->n_total = n;
@@ -370,11 +407,206 @@ static int dist_prepare(nbe_engine* e)
     return NBE_OK;
 }
 
+// ---- frames of a distributed run ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void frame_narrow_kernel(const double4* __restrict__ posm, float4* __restrict__ out, int n)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const double4 p = posm[i];
+    out[i] = make_float4((float)p.x, (float)p.y, (float)p.z, (float)p.w);
+}
+
+static void dist_frames_deliver(nbe_engine* e)
+{
+    DistMulti* d = e->multi->dist;
+    DistFrames& fs = d->frames;
+    for (;;) {
+        int slot;
+        {
+            std::unique_lock<std::mutex> lk(fs.mu);
+            fs.cv_work.wait(lk, [&] { return fs.stop || !fs.queue.empty(); });
+            if (fs.queue.empty()) return;            // stop requested and nothing left to deliver
+            slot = fs.queue.front();
+            fs.queue.pop_front();
+        }
+        DistFrameSlot& s = fs.slots[(size_t)slot];
+        for (hipEvent_t ev : s.done) (void)hipEventSynchronize(ev);
+        fs.ids_scratch.resize(s.n);
+        for (size_t k = 0; k < s.n; k++) fs.ids_scratch[k] = s.orig[k] < d->ids.size() ? d->ids[s.orig[k]] : (uint64_t)s.orig[k];
+        fs.cb(fs.user, s.frame, s.n, s.xyzm, nullptr, fs.ids_scratch.data());
+        {
+            std::lock_guard<std::mutex> lk(fs.mu);
+            s.busy = false;
+        }
+        fs.cv_free.notify_all();
+    }
+}
+
+static void dist_frames_release(nbe_engine* e)
+{
+    MultiState* m = e->multi;
+    DistFrames& fs = m->dist->frames;
+    for (size_t g = 0; g < m->subs.size(); g++) {
+        (void)hipSetDevice(m->devs[g]);
+        if (g < fs.side.size() && fs.side[g]) { (void)hipStreamSynchronize(fs.side[g]); (void)hipStreamDestroy(fs.side[g]); }
+        if (g < fs.snap_xyzm.size() && fs.snap_xyzm[g]) (void)hipFree(fs.snap_xyzm[g]);
+        if (g < fs.snap_orig.size() && fs.snap_orig[g]) (void)hipFree(fs.snap_orig[g]);
+        if (g < fs.snapped.size() && fs.snapped[g]) (void)hipEventDestroy(fs.snapped[g]);
+        if (g < fs.sent.size() && fs.sent[g]) (void)hipEventDestroy(fs.sent[g]);
+        for (DistFrameSlot& s : fs.slots)
+            if (g < s.done.size() && s.done[g]) (void)hipEventDestroy(s.done[g]);
+    }
+    for (DistFrameSlot& s : fs.slots) {
+        if (s.xyzm) (void)hipHostFree(s.xyzm);
+        if (s.orig) (void)hipHostFree(s.orig);
+    }
+    fs.slots.clear();
+    fs.side.clear(); fs.snap_xyzm.clear(); fs.snap_orig.clear(); fs.snapped.clear(); fs.sent.clear(); fs.sending.clear();
+}
+
+static int dist_frames_allocate(nbe_engine* e, int slots)
+{
+    MultiState* m = e->multi;
+    DistMulti* d = m->dist;
+    DistFrames& fs = d->frames;
+    const size_t G = m->subs.size();
+    const size_t total = d->n_total > 0 ? d->n_total : 1;
+    fs.side.assign(G, nullptr); fs.snap_xyzm.assign(G, nullptr); fs.snap_orig.assign(G, nullptr);
+    fs.snapped.assign(G, nullptr); fs.sent.assign(G, nullptr); fs.sending.assign(G, 0);
+    fs.slots.assign((size_t)slots, DistFrameSlot());
+    for (DistFrameSlot& s : fs.slots) s.done.assign(G, nullptr);
+    for (size_t g = 0; g < G; g++) {
+        NBE_HIP(hipSetDevice(m->devs[g]));
+        const size_t cap = g < d->capacity.size() && d->capacity[g] > 0 ? d->capacity[g] : 1;
+        NBE_HIP(hipStreamCreateWithFlags(&fs.side[g], hipStreamNonBlocking));
+        NBE_HIP(hipMalloc((void**)&fs.snap_xyzm[g], cap * sizeof(float4)));
+        NBE_HIP(hipMalloc((void**)&fs.snap_orig[g], cap * sizeof(uint32_t)));
+        NBE_HIP(hipEventCreateWithFlags(&fs.snapped[g], hipEventDisableTiming));
+        NBE_HIP(hipEventCreateWithFlags(&fs.sent[g], hipEventDisableTiming));
+        for (DistFrameSlot& s : fs.slots) NBE_HIP(hipEventCreateWithFlags(&s.done[g], hipEventDisableTiming));
+    }
+    for (DistFrameSlot& s : fs.slots) {
+        NBE_HIP(hipHostMalloc((void**)&s.xyzm, total * 4 * sizeof(float), hipHostMallocPortable));
+        NBE_HIP(hipHostMalloc((void**)&s.orig, total * sizeof(uint32_t), hipHostMallocPortable));
+    }
+    return NBE_OK;
+}
+
+int multi_dist_frames_begin(nbe_engine* e, int every, int slots, int first_frame, nbe_frame_cb cb, void* user)
+{
+    MultiState* m = e->multi;
+    DistFrames& fs = m->dist->frames;
+    if (every < 1 || slots < 1 || slots > 1024) { nbe_set_error("every must be >= 1 and slots in 1..1024"); return NBE_E_INVALID; }
+    if (fs.active) { nbe_set_error("frame streaming is already on"); return NBE_E_INVALID; }
+    fs.every = every; fs.first_frame = first_frame; fs.cb = cb; fs.user = user;
+    fs.step_base = m->subs[0]->stats.steps;
+    fs.have_last = false; fs.stop = false;
+    fs.queue.clear();
+    int rc;
+    try {
+        rc = dist_frames_allocate(e, slots);
+        if (rc == NBE_OK) {
+            fs.active = true;
+            fs.worker = std::thread(dist_frames_deliver, e);
+        }
+    } catch (const std::exception& ex) {
+        nbe_set_error("frame streaming could not start: %s", ex.what());
+        rc = NBE_E_NOMEM;
+    }
+    if (rc != NBE_OK) {
+        fs.active = false;
+        dist_frames_release(e);
+    }
+    return rc;
+}
+
+int multi_dist_frames_end(nbe_engine* e)
+{
+    DistFrames& fs = e->multi->dist->frames;
+    if (!fs.active) return NBE_OK;
+    {
+        std::lock_guard<std::mutex> lk(fs.mu);
+        fs.stop = true;
+    }
+    fs.cv_work.notify_all();
+    if (fs.worker.joinable()) fs.worker.join();      // delivers everything still queued first
+    dist_frames_release(e);
+    fs.active = false;
+    return NBE_OK;
+}
+
+// Called at the top of every step: the bodies as the step is about to read them.  Between a build and the next classify
+// a GPU's bodies fill its first slots in key order, and the GPUs follow each other in key order.
+static int dist_frames_before_step(nbe_engine* e)
+{
+    MultiState* m = e->multi;
+    DistMulti* d = m->dist;
+    DistFrames& fs = d->frames;
+    if (!fs.active) return NBE_OK;
+    const uint64_t k = m->subs[0]->stats.steps - fs.step_base;
+    if (k % (uint64_t)fs.every != 0) return NBE_OK;
+    if (fs.have_last && fs.last_k == k) return NBE_OK;
+    const size_t G = m->subs.size();
+    std::vector<size_t> live(G, 0);
+    size_t total = 0;
+    for (size_t g = 0; g < G; g++) { live[g] = dist_live_slots(m->subs[g]); total += live[g]; }
+    if (total == 0) return NBE_OK;
+    if (total > d->n_total) { nbe_set_error("the GPUs hold %zu bodies of %zu", total, d->n_total); return NBE_E_DEVICE; }
+    fs.have_last = true; fs.last_k = k;
+    int slot = -1;
+    {
+        std::unique_lock<std::mutex> lk(fs.mu);      // back-pressure: wait for a free buffer like a full channel
+        fs.cv_free.wait(lk, [&] {
+            for (size_t i = 0; i < fs.slots.size(); i++)
+                if (!fs.slots[i].busy) { slot = (int)i; return true; }
+            return false;
+        });
+        fs.slots[(size_t)slot].busy = true;
+    }
+    DistFrameSlot& s = fs.slots[(size_t)slot];
+    s.frame = fs.first_frame + (int)(k / (uint64_t)fs.every);
+    s.n = total;
+    size_t at = 0;
+    for (size_t g = 0; g < G; g++) {
+        nbe_engine* sub = m->subs[g];
+        const size_t n = live[g];
+        NBE_HIP(hipSetDevice(m->devs[g]));
+        if (fs.sending[g]) NBE_HIP(hipStreamWaitEvent(sub->stream, fs.sent[g], 0));      // the snapshot is still being sent
+        if (n > 0) {
+            if (sub->state64) {
+                hipLaunchKernelGGL(frame_narrow_kernel, dim3(cdiv(n, 256)), dim3(256), 0, sub->stream, (const double4*)sub->posm[sub->cur],
+                                   fs.snap_xyzm[g], (int)n);
+                NBE_HIP(hipGetLastError());
+            } else {
+                NBE_HIP(hipMemcpyAsync(fs.snap_xyzm[g], sub->posm[sub->cur], n * sizeof(float4), hipMemcpyDeviceToDevice, sub->stream));
+            }
+            NBE_HIP(hipMemcpyAsync(fs.snap_orig[g], sub->orig[sub->orig_cur], n * sizeof(uint32_t), hipMemcpyDeviceToDevice, sub->stream));
+        }
+        NBE_HIP(hipEventRecord(fs.snapped[g], sub->stream));
+        NBE_HIP(hipStreamWaitEvent(fs.side[g], fs.snapped[g], 0));
+        if (n > 0) {
+            NBE_HIP(hipMemcpyAsync(s.xyzm + 4 * at, fs.snap_xyzm[g], n * sizeof(float4), hipMemcpyDeviceToHost, fs.side[g]));
+            NBE_HIP(hipMemcpyAsync(s.orig + at, fs.snap_orig[g], n * sizeof(uint32_t), hipMemcpyDeviceToHost, fs.side[g]));
+        }
+        NBE_HIP(hipEventRecord(s.done[g], fs.side[g]));
+        NBE_HIP(hipEventRecord(fs.sent[g], fs.side[g]));
+        fs.sending[g] = 1;
+        at += n;
+    }
+    {
+        std::lock_guard<std::mutex> lk(fs.mu);
+        fs.queue.push_back(slot);
+    }
+    fs.cv_work.notify_one();
+    return NBE_OK;
+}
+
 static int dist_step(nbe_engine* e, int nsteps)
 {
     MultiState* m = e->multi;
     DistMulti* d = m->dist;
     for (int s = 0; s < nsteps; s++) {
+        NBE_TRY(dist_frames_before_step(e));
         if (!d->prepared) NBE_TRY(dist_prepare(e));
         NBE_TRY(d->pool.run([&](int r) -> int { return nbe_dist_advance(m->subs[(size_t)r]); }));
         d->prepared = false;

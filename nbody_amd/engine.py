@@ -283,8 +283,9 @@ class Engine:
             if radius:
                 r = np.ctypeslib.as_array(radius, shape=(n,)).copy() if n else np.zeros(0, np.float32)
             callback(frame, a, i, r)
-        self._frame_cb = FRAME_CB(tramp)          # keep the thunk alive while streaming
-        self._check(self._lib.nbe_frame_stream_begin(self._h, int(every), int(slots), int(first_frame), self._frame_cb, None))
+        thunk = FRAME_CB(tramp)
+        self._check(self._lib.nbe_frame_stream_begin(self._h, int(every), int(slots), int(first_frame), thunk, None))
+        self._frame_cb = thunk                    # keep the thunk alive while streaming (a refused call leaves the old one in place)
 
     def frame_stream_end(self):
         self._check(self._lib.nbe_frame_stream_end(self._h))

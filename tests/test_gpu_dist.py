@@ -325,6 +325,45 @@ def test_distributed_tree_behind_one_engine_handle(gpu, precision, n, devices):
     assert abs(ke - ke1) <= 1e-6 * ke1 and abs(pe - pe1) <= 5e-3 * abs(pe1)
 
 
+@pytest.mark.parametrize("precision,devices", [("f32", [0, 0, 0]), ("mixed", [0, 0])])
+def test_frame_stream_of_a_distributed_engine(gpu, precision, devices):
+    """main.go:90-101 on the distributed tree: no GPU holds all bodies, every GPU sends its own into one frame.  The
+    frames carry the bodies as each step is about to read them: the same rows (by id) as one engine streams, and frame k
+    is the state that a download after k * every steps returns, narrowed to fp32."""
+    n, every, nsteps = 6001, 2, 7
+    b = physics.plummer(n, seed=4, a=2e3)
+    ids = np.arange(n, dtype=np.uint64) * 3 + 7
+    got = {}
+    with Engine(mode="tree", precision=precision, theta=0.6, devices=devices, distributed=True) as e:
+        e.upload(b.pos, b.vel, b.mass, ids=ids)
+        e.frame_stream_begin(lambda f, xyzm, i, r: got.__setitem__(f, (xyzm.copy(), i.copy(), r)), every=every, slots=2, first_frame=5)
+        with pytest.raises(EngineError, match="already on"):
+            e.frame_stream_begin(lambda *a: None)
+        e.step(nsteps)
+        e.frame_stream_end()
+        e.step(1)                                 # streaming is over: no further frame
+        e.frame_stream_end()                      # ending twice is harmless
+    assert sorted(got) == [5, 6, 7, 8]            # steps 0, 2, 4, 6
+    want = {}
+    with Engine(mode="tree", precision=precision, theta=0.6, tree_sums=True) as one:
+        one.upload(b.pos, b.vel, b.mass, ids=ids)
+        one.frame_stream_begin(lambda f, xyzm, i, r: want.__setitem__(f, (xyzm.copy(), i.copy())), every=every, slots=2, first_frame=5)
+        one.step(nsteps)
+        one.frame_stream_end()
+    for f in sorted(want):
+        xyzm, i, r = got[f]
+        assert r is None and len(i) == n
+        o, ow = np.argsort(i), np.argsort(want[f][1])
+        assert np.array_equal(i[o], want[f][1][ow])
+        if precision == "f32":
+            assert np.array_equal(xyzm[o], want[f][0][ow])
+        else:
+            assert np.abs(xyzm[o] - want[f][0][ow]).max() <= 1e-6 * np.abs(want[f][0]).max()
+    # the first frame is the upload itself
+    o = np.argsort(got[5][1])
+    assert np.array_equal(got[5][0][o][:, :3], b.pos.astype(np.float32))
+
+
 def test_distributed_needs_several_devices_and_tree_mode(gpu):
     with pytest.raises(EngineError, match="num_devices > 1"):
         Engine(mode="tree", distributed=True)

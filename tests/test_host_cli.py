@@ -142,3 +142,25 @@ def test_host_asgo_run_equals_the_reference_configuration_of_the_oracle(gpu, tmp
     assert np.abs(p2 - rp[k]).max() <= 1e-10 * np.abs(rp[k]).max()
     assert np.abs(v2 - rv[k]).max() <= 1e-10 * np.abs(rv[k]).max()
     assert np.allclose(p2[k == n - 1][0], b.pos[n - 1] + 9 * 3600.0 * b.vel[n - 1], rtol=1e-14, atol=0)
+
+
+@pytest.mark.gpu
+def test_host_distributed_tree_streams_the_frames_of_one_gpu(gpu, tmp_path):
+    """-distributed (several shards on this one GPU through -devices): no shard holds all bodies and every frame is
+    gathered from all of them; the frame files hold the rows of a one-GPU run (by id, fp32 tree: the same bits when the
+    one GPU sums its cells child by child, to rounding against the default prefix sums)."""
+    common = ["-n", "4000", "-y", "0.002", "-nocollision", "-tree", "-seed", "9", "-theta", "0.6"]      # frames = 17
+    r = run(common + ["-devices", "0,0,0", "-distributed", "-frames-dir", "dist"], tmp_path)
+    assert r.returncode == 0, r.stdout.decode()
+    r = run(common + ["-frames-dir", "one"], tmp_path)
+    assert r.returncode == 0, r.stdout.decode()
+    files = sorted(os.listdir(tmp_path / "dist"))
+    assert files == sorted(os.listdir(tmp_path / "one")) == [f"{k:010d}.frame" for k in range(18)]
+    for name in (files[0], files[9], files[17]):
+        a, b = read_frame(tmp_path / "dist" / name), read_frame(tmp_path / "one" / name)
+        a, b = a[np.argsort(a["id"])], b[np.argsort(b["id"])]
+        assert np.array_equal(a["id"], b["id"]) and 3900 < len(a) <= 4002        # (a few bodies leave the bound, in both runs alike)
+        assert np.abs(a["xyzmr"] - b["xyzmr"]).max() <= 1e-5 * np.abs(b["xyzmr"][:, :3]).max()
+    first = read_frame(tmp_path / "dist" / files[0])
+    one = read_frame(tmp_path / "one" / files[0])
+    assert np.array_equal(first[np.argsort(first["id"])]["xyzmr"], one[np.argsort(one["id"])]["xyzmr"])
