@@ -129,7 +129,11 @@ __device__ __forceinline__ bool node_opens(const RawD& nd, double r2, double the
 // Keeping the sit-out state as wave masks in scalar registers (sleeping lanes' masks on a small stack, pushed when
 // a cell is opened by some lanes and accepted by others) takes the vector instructions per visit from 17 to 13 and
 // adds nine scalar ones: 2.15 ms, no change (2.8 ms when combined with the early request described below: its
-// pushes and pops are branches inside the visit).  Two bodies per lane behind one shared cursor (128 bodies per wave,
+// pushes and pops are branches inside the visit; measured again on the issue-bound kernel in the cheapest form there is:
+// a sleeping lane carries +infinity as its floor under r^2, so it neither opens nor receives and the visit has no awake
+// test, no masked distance and no sit-out update, 13 vector instructions, with the sleep and wake events as uniform
+// branches around a stack of cell ends in the lanes of a register: 1.90 / 3.63 / 32.6 ms at 1M / 2M / 16M bodies
+// against 1.87 / 3.67 / 32.6).  Two bodies per lane behind one shared cursor (128 bodies per wave,
 // 0.58 times the visits, twice the arithmetic per visit): 2.57 ms.  Fetching the node with a vector load of eight
 // lanes and v_readlane instead of the scalar load: 2.9 ms.  The time scales with the waves resident per SIMD
 // (1, 2, 4, 8 waves: 10.2, 5.7, 3.2, 2.16 ms), i.e. one visit is a dependent chain of about 390 cycles (scalar load,
