@@ -61,6 +61,8 @@ __device__ __forceinline__ RawF arrived(PendingF& p)
     asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(p.v));
     return RawF{p.v[0], p.v[1], p.v[2], p.v[3], p.v[4], (int)p.v[5]};
 }
+__device__ __forceinline__ void settle(PendingF& p, PendingF& q) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(p.v), "+s"(q.v)); }
+__device__ __forceinline__ void settle(PendingD&, PendingD&) {}
 __device__ __forceinline__ void settle(PendingF& p) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(p.v)); }
 __device__ __forceinline__ void settle(PendingD&) {}
 __device__ __forceinline__ PendingD request_raw(const NodeD* __restrict__ nodes, int i, double&) { return PendingD{load_raw(nodes, i)}; }
@@ -249,9 +251,10 @@ __global__ __launch_bounds__(WALK_BLOCK) void walk_kernel(
             fx = 0; fy = 0; fz = 0;
         }
         cur = next;
+        if constexpr (!BLOCKED) return next < total;
+        // (mixed precision: with the wait behind the loop the compiler copies the record registers around the flush of
+        // the partial sums while a request is in flight, which the build's check of the assembly rejects)
         if (next < total) return true;
-        // The record requested last is never read.  It still has to land before its registers may serve anything
-        // else: waiting here, with the slot as operand, keeps them reserved on the way out.
         settle(there);
         return false;
     };
@@ -262,6 +265,9 @@ __global__ __launch_bounds__(WALK_BLOCK) void walk_kernel(
         if (!visit(slot_a, slot_b)) break;
         if (!visit(slot_b, slot_a)) break;
     }
+    // The record requested last is never read.  It still has to land before its registers may serve anything else:
+    // waiting here, with both slots as operands, keeps them reserved on the way out of the loop.
+    if constexpr (!BLOCKED) settle(slot_a, slot_b);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // nothing is in flight here; states it on every path out of the loop
 
     if (COUNT && (threadIdx.x & 63) == 0 && interactions) {
