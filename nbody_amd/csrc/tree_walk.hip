@@ -131,11 +131,12 @@ __device__ __forceinline__ bool node_opens(const RawD& nd, double r2, double the
 // Keeping the sit-out state as wave masks in scalar registers (sleeping lanes' masks on a small stack, pushed when
 // a cell is opened by some lanes and accepted by others) takes the vector instructions per visit from 17 to 13 and
 // adds nine scalar ones: 2.15 ms, no change (2.8 ms when combined with the early request described below: its
-// pushes and pops are branches inside the visit; measured again on the issue-bound kernel in the cheapest form there is:
-// a sleeping lane carries +infinity as its floor under r^2, so it neither opens nor receives and the visit has no awake
-// test, no masked distance and no sit-out update, 13 vector instructions, with the sleep and wake events as uniform
-// branches around a stack of cell ends in the lanes of a register: 1.90 / 3.63 / 32.6 ms at 1M / 2M / 16M bodies
-// against 1.87 / 3.67 / 32.6).  Two bodies per lane behind one shared cursor (128 bodies per wave,
+// pushes and pops are branches inside the visit).  What ships now is the cheapest form of that idea, see "sleeping
+// lanes" below: 12 vector instructions per visit instead of 17.5, 1.78 / 3.49 / 31.7 ms at 1M / 2M / 16M bodies
+// against 1.87 / 3.67 / 32.6; it paid only after the loop's scalar instructions had been cut from 16.5 to 11.5 per
+// visit (the wait for the last request behind the loop: no gain by itself either; with 17 scalar instructions the
+// 13-instruction visit took 1.90 ms): vector and scalar instructions have to fall together.
+// Two bodies per lane behind one shared cursor (128 bodies per wave,
 // 0.58 times the visits, twice the arithmetic per visit): 2.57 ms.  Fetching the node with a vector load of eight
 // lanes and v_readlane instead of the scalar load: 2.9 ms.  The time scales with the waves resident per SIMD
 // (1, 2, 4, 8 waves: 10.2, 5.7, 3.2, 2.16 ms), i.e. one visit is a dependent chain of about 390 cycles (scalar load,
@@ -198,10 +199,18 @@ __global__ __launch_bounds__(WALK_BLOCK) void walk_kernel(
     // tail_orig (NBE_QUIRK_DROP_TAIL): bodies whose upload index is tail_limit or more are not walked, like the
     // last n mod 4 bodies of main.go:134-148; they sit out the whole traversal and are integrated with zero force
     const bool walked = valid && !(tail_orig && tail_orig[i] >= tail_limit);
-    int my_skip = walked ? 0 : 0x7fffffff;        // the lane sits out while cursor < my_skip
+    int my_skip = walked ? 0 : 0x7fffffff;        // the lane sleeps while cursor < my_skip
     // a vector instruction that reads a scalar register issues at half rate: keep the loop's constant in a vector one
     R floor2v = floor2;
     asm volatile("" : "+v"(floor2v));
+    // Sleeping lanes.  A lane that sits out carries +infinity where the others carry the floor under r^2: its distance
+    // to every node is infinite, so it opens nothing and receives nothing (rsq(inf) = 0), without a test of its own in
+    // the visit.  Lanes fall asleep only where the cursor descends into a cell that they accept, and wake where the
+    // cursor leaves that cell; both are events of the whole wave, decided on scalar values, and rare (about a sixth of
+    // the visits each).  The ends of the cells in which lanes sleep are nested: the innermost in next_wake, the ones
+    // around it on a stack kept in the lanes of one vector register (at most one entry per depth of the tree).
+    R seed = walked ? floor2v : (R)INFINITY;
+    int next_wake = 0x7fffffff, sp = 0, ends = 0;
     unsigned count = 0;
     int it = 0;
     // The cursor and the node under it live in scalar registers: one scalar load per visit.  A visit is a chain of
@@ -215,30 +224,57 @@ __global__ __launch_bounds__(WALK_BLOCK) void walk_kernel(
     auto visit = [&](auto& here, auto& there) -> bool {
         const auto nd = arrived(here);
         const int skip = nd.skip;
+        // (the compare must not move up in front of the wait for the record: on the way out of the loop it would share
+        // its registers with a request that is still in flight)
+        asm volatile("" : "+s"(cur));
+        // (waking the lanes for the next node at the end of the visit, under the request in flight, was slower: 1.82
+        // against 1.78 ms at 1M bodies)
+        if (cur == next_wake) {                   // the cursor leaves the innermost cell in which lanes sleep
+            if (my_skip <= cur) seed = floor2v;
+            --sp;
+            next_wake = __builtin_amdgcn_readlane(ends, sp);
+        }
         const R dx = as_real(nd.x) - px, dy = as_real(nd.y) - py, dz = as_real(nd.z) - pz;
         // The floor under r^2 (1e-12 m^2 unless softening is on) keeps rsq finite for the body's own leaf
         // and for bodies at distance 0, which then contribute exactly 0 because dx = dy = dz = 0.
-        R r2 = fma(dx, dx, fma(dy, dy, fma(dz, dz, floor2v)));
-        const bool active = cur >= my_skip;
-        // lanes sitting out get an infinite distance, so one compare is both the opening test and the vote
-        const R rtest = active ? (SOFT ? r2 - floor2v : r2) : (R)INFINITY;
+        R r2 = fma(dx, dx, fma(dy, dy, fma(dz, dz, seed)));
+        // sleeping lanes have an infinite distance, so one compare is both the opening test and the vote
+        const R rtest = SOFT ? r2 - floor2v : r2;
         const bool open = node_opens(nd, rtest, theta);
-        const int next = __builtin_amdgcn_ballot_w64(open) != 0 ? cur + 1 : skip;
+        const unsigned long long opening = __builtin_amdgcn_ballot_w64(open);
+        const int next = opening != 0 ? cur + 1 : skip;
         there = request_raw(nodes, next, r2);      // the force arithmetic below runs while this is in flight
         const R mass = as_real(nd.m);
-        const bool take = active && !open;
-        if (take) my_skip = skip;
+        bool counted = false;
+        if (COUNT) counted = !open && r2 < (R)INFINITY && (dx != (R)0 || dy != (R)0 || dz != (R)0);
+        if (opening != 0) {
+            // the cursor descends: the lanes that accept the cell sleep until the cursor reaches its end
+            const bool rest = !open && r2 < (R)INFINITY;
+            if (__builtin_amdgcn_ballot_w64(rest) != 0) {
+                if (rest) { my_skip = skip; seed = (R)INFINITY; }
+                if (skip != next_wake) {           // (a last child ends where its parent ends: one wake for both)
+                    if ((int)(threadIdx.x & 63u) == sp) ends = next_wake;
+                    ++sp;
+                    next_wake = skip;
+                }
+            }
+            // a lane that opens the cell takes nothing from it: an infinite distance gives it the weight 0
+            // (not in mixed precision, where the compiler then copies record registers with a request in flight)
+            if constexpr (!BLOCKED) if (open) r2 = (R)INFINITY;
+        }
         const R rinv = rsq_dev(r2);
         R rinv2 = rinv * rinv;
         // (keeps the compiler from pairing the two products in one packed multiply, for which it copies the mass
         // to a vector register: one more instruction that reads a scalar register)
         if (__is_same(R, float)) asm volatile("" : "+v"(rinv2));
-        const R w = take ? rinv2 * (rinv * mass) : (R)0;
+        // (fp64: the Newton step behind v_rsq_f64 turns rsq(inf) = 0 into NaN, so those lanes are masked by hand)
+        const bool none = BLOCKED ? open : (!__is_same(R, float) && !(r2 < (R)INFINITY));
+        const R w = none ? (R)0 : rinv2 * (rinv * mass);
         fx = fma(dx, w, fx);
         fy = fma(dy, w, fy);
         fz = fma(dz, w, fz);
         if (COUNT) {
-            const bool use = take && (dx != (R)0 || dy != (R)0 || dz != (R)0);
+            const bool use = counted;
             count += (unsigned)__popcll(__builtin_amdgcn_ballot_w64(use));
             if (use) phi += (A)(rinv * mass);
         }
