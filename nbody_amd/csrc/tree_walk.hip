@@ -139,8 +139,9 @@ __device__ __forceinline__ bool node_opens(const RawD& nd, double r2, double the
 // Two bodies per lane behind one shared cursor (128 bodies per wave,
 // 0.58 times the visits, twice the arithmetic per visit): 2.57 ms.  Fetching the node with a vector load of eight
 // lanes and v_readlane instead of the scalar load: 2.9 ms.  The time scales with the waves resident per SIMD
-// (1, 2, 4, 8 waves: 10.2, 5.7, 3.2, 2.16 ms), i.e. one visit is a dependent chain of about 390 cycles (scalar load,
-// arithmetic, vote, branch) and eight waves, the hardware's limit, overlap it to about 80 cycles per visit and SIMD.
+// (1, 2, 4, 8 waves: 10.2, 5.7, 3.2, 2.16 ms; the kernel as it is now: 1, 2, 4, 6, 8 waves: 8.06, 4.44, 2.61, 2.07,
+// 1.77 ms), i.e. one visit is a dependent chain of about 390 (now 306) cycles (scalar load, arithmetic, vote, branch)
+// and eight waves, the hardware's limit, overlap it to about 80 (now 67) cycles per visit and SIMD.
 // Shortening that chain is what helps: requesting the next node right after the vote, so that the force arithmetic
 // runs under the load, gives 1.97 ms (2.15 ms with the load at the top of the visit).  After that the visit is
 // bound by instruction issue, where a vector instruction costs twice as much when it reads a scalar register:
