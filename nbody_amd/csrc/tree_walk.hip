@@ -229,7 +229,8 @@ __global__ __launch_bounds__(WALK_BLOCK) void walk_kernel(
         // its registers with a request that is still in flight)
         asm volatile("" : "+s"(cur));
         // (waking the lanes for the next node at the end of the visit, under the request in flight, was slower: 1.82
-        // against 1.78 ms at 1M bodies)
+        // against 1.78 ms at 1M bodies; so was a cursor that counts bytes, which takes the shift out of the chain from
+        // the vote to the request: 1.80 / 3.61 / 32.3 ms against 1.79 / 3.48 / 31.8 at 1M / 2M / 16M)
         if (cur == next_wake) {                   // the cursor leaves the innermost cell in which lanes sleep
             if (my_skip <= cur) seed = floor2v;
             --sp;
