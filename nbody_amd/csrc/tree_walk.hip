@@ -210,7 +210,11 @@ __global__ __launch_bounds__(WALK_BLOCK) void walk_kernel(
     // cursor leaves that cell; both are events of the whole wave, decided on scalar values, and rare (about a sixth of
     // the visits each).  The ends of the cells in which lanes sleep are nested: the innermost in next_wake, the ones
     // around it on a stack kept in the lanes of one vector register (at most one entry per depth of the tree).
-    R seed = walked ? floor2v : (R)INFINITY;
+    // Mixed precision keeps the per-lane test of the sit-out index in every visit (17 vector instructions): there the
+    // events made the kernel slower at 16M bodies (two galaxies: 37.6 against 36.0 ms), and without the explicit mask on
+    // the weight the compiler copies record registers while a request is in flight.
+    constexpr bool EVENTS = !BLOCKED;
+    R seed = (walked || !EVENTS) ? floor2v : (R)INFINITY;
     int next_wake = 0x7fffffff, sp = 0, ends = 0;
     unsigned count = 0;
     int it = 0;
@@ -231,7 +235,7 @@ __global__ __launch_bounds__(WALK_BLOCK) void walk_kernel(
         // (waking the lanes for the next node at the end of the visit, under the request in flight, was slower: 1.82
         // against 1.78 ms at 1M bodies; so was a cursor that counts bytes, which takes the shift out of the chain from
         // the vote to the request: 1.80 / 3.61 / 32.3 ms against 1.79 / 3.48 / 31.8 at 1M / 2M / 16M)
-        if (cur == next_wake) {                   // the cursor leaves the innermost cell in which lanes sleep
+        if (EVENTS && cur == next_wake) {         // the cursor leaves the innermost cell in which lanes sleep
             if (my_skip <= cur) seed = floor2v;
             --sp;
             next_wake = __builtin_amdgcn_readlane(ends, sp);
@@ -241,15 +245,18 @@ __global__ __launch_bounds__(WALK_BLOCK) void walk_kernel(
         // and for bodies at distance 0, which then contribute exactly 0 because dx = dy = dz = 0.
         R r2 = fma(dx, dx, fma(dy, dy, fma(dz, dz, seed)));
         // sleeping lanes have an infinite distance, so one compare is both the opening test and the vote
-        const R rtest = SOFT ? r2 - floor2v : r2;
+        const bool active = EVENTS || cur >= my_skip;
+        const R rtest = active ? (SOFT ? r2 - floor2v : r2) : (R)INFINITY;
         const bool open = node_opens(nd, rtest, theta);
         const unsigned long long opening = __builtin_amdgcn_ballot_w64(open);
         const int next = opening != 0 ? cur + 1 : skip;
         there = request_raw(nodes, next, r2);      // the force arithmetic below runs while this is in flight
         const R mass = as_real(nd.m);
         bool counted = false;
-        if (COUNT) counted = !open && r2 < (R)INFINITY && (dx != (R)0 || dy != (R)0 || dz != (R)0);
-        if (opening != 0) {
+        if (COUNT) counted = active && !open && r2 < (R)INFINITY && (dx != (R)0 || dy != (R)0 || dz != (R)0);
+        const bool take = active && !open;
+        if (!EVENTS && take) my_skip = skip;
+        if (EVENTS && opening != 0) {
             // the cursor descends: the lanes that accept the cell sleep until the cursor reaches its end
             const bool rest = !open && r2 < (R)INFINITY;
             if (__builtin_amdgcn_ballot_w64(rest) != 0) {
@@ -261,8 +268,7 @@ __global__ __launch_bounds__(WALK_BLOCK) void walk_kernel(
                 }
             }
             // a lane that opens the cell takes nothing from it: an infinite distance gives it the weight 0
-            // (not in mixed precision, where the compiler then copies record registers with a request in flight)
-            if constexpr (!BLOCKED) if (open) r2 = (R)INFINITY;
+            if (open) r2 = (R)INFINITY;
         }
         const R rinv = rsq_dev(r2);
         R rinv2 = rinv * rinv;
@@ -270,7 +276,7 @@ __global__ __launch_bounds__(WALK_BLOCK) void walk_kernel(
         // to a vector register: one more instruction that reads a scalar register)
         if (__is_same(R, float)) asm volatile("" : "+v"(rinv2));
         // (fp64: the Newton step behind v_rsq_f64 turns rsq(inf) = 0 into NaN, so those lanes are masked by hand)
-        const bool none = BLOCKED ? open : (!__is_same(R, float) && !(r2 < (R)INFINITY));
+        const bool none = !EVENTS ? !take : (!__is_same(R, float) && !(r2 < (R)INFINITY));
         const R w = none ? (R)0 : rinv2 * (rinv * mass);
         fx = fma(dx, w, fx);
         fy = fma(dy, w, fy);
