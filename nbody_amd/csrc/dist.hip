@@ -81,7 +81,7 @@ struct DistState {
     void* export_nodes = nullptr;
     size_t export_cap = 0;
     unsigned long long* d_export_base = nullptr;   // [0, world] first exported node per destination and the end; then two batch bases
-    int* d_export_sizes = nullptr;      // world x NBE_DIST_MAX_FRAGMENTS
+    int* d_export_sizes = nullptr;      // [world][fragments of this rank], room for world x NBE_DIST_MAX_FRAGMENTS
     int* d_frag_bodies = nullptr;       // [MAX_FRAGMENTS][2]: first body and one past the last body of every fragment
     double* d_boxes = nullptr;          // world x (MAX_BOXES + 1) x 6: a rank's boxes, then the box around them all
     std::vector<double> boxes_host;
@@ -836,7 +836,7 @@ __global__ __launch_bounds__(256) void export_sizes_kernel(const uint32_t* __res
         }
     }
     if (f < nfrag)
-        sizes[(size_t)q * NBE_DIST_MAX_FRAGMENTS + f] = (int)(export_place(blockoff, rank8, nblk, j, (size_t)frags[f].start + frags[f].nodes) -
+        sizes[(size_t)q * nfrag + f] = (int)(export_place(blockoff, rank8, nblk, j, (size_t)frags[f].start + frags[f].nodes) -
                                                               export_place(blockoff, rank8, nblk, j, (size_t)frags[f].start));
 }
 
@@ -893,7 +893,7 @@ static int export_t(nbe_engine* e, int32_t* export_sizes, uint64_t* export_offse
     unsigned long long* batch_base = d->d_export_base + (W + 1);      // two device scalars used in turn
     NBE_HIP(hipMemsetAsync(d->d_export_base, 0, (size_t)(W + 3) * sizeof(unsigned long long), e->stream));
     NBE_HIP(hipMemsetAsync(d->d_nfrag + 1, 0, sizeof(int), e->stream));
-    NBE_HIP(hipMemsetAsync(d->d_export_sizes, 0, (size_t)W * NBE_DIST_MAX_FRAGMENTS * sizeof(int), e->stream));
+    NBE_HIP(hipMemsetAsync(d->d_export_sizes, 0, (size_t)W * (size_t)std::max(nf, 1) * sizeof(int), e->stream));
     if (nf) NBE_HIP(hipMemcpyAsync(d->d_frags, d->my_frags.data(), (size_t)nf * sizeof(nbe_fragment_t), hipMemcpyHostToDevice, e->stream));
     std::vector<int> others;
     for (int q = 0; q < W; q++)
@@ -924,10 +924,8 @@ static int export_t(nbe_engine* e, int32_t* export_sizes, uint64_t* export_offse
     int* h_sizes = d->h_small + 16 + 2 * (W + 1);
     NBE_HIP(hipMemcpyAsync(h_base, d->d_export_base, (size_t)(W + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost, e->stream));
     NBE_HIP(hipMemcpyAsync(d->h_small, d->d_nfrag, 2 * sizeof(int), hipMemcpyDeviceToHost, e->stream));
-    if (nf)
-        for (int q = 0; q < W; q++)
-            NBE_HIP(hipMemcpyAsync(h_sizes + (size_t)q * nf, d->d_export_sizes + (size_t)q * NBE_DIST_MAX_FRAGMENTS, (size_t)nf * sizeof(int),
-                                   hipMemcpyDeviceToHost, e->stream));
+    if (nf)      // (the kernel packs them [destination][fragment] without gaps, so one copy fetches all)
+        NBE_HIP(hipMemcpyAsync(h_sizes, d->d_export_sizes, (size_t)W * nf * sizeof(int), hipMemcpyDeviceToHost, e->stream));
     NBE_HIP(hipStreamSynchronize(e->stream));
     if (d->h_small[1]) { nbe_set_error("rank %d: the export buffer (%zu nodes) is too small", d->rank, d->export_cap); return NBE_E_NOMEM; }
     // destinations were written in rank order; a rank that gets nothing (this one) starts where the next one starts
