@@ -116,6 +116,10 @@ extern "C" int nbe_create(const nbe_config* cfg, nbe_engine** out)
         const long v = strtol(env, nullptr, 10);
         if (v >= 0 && v < e->small_max) e->small_max = (int)v;
     }
+    if (const char* env = getenv("NBODY_WALK_BODIES_PER_LANE")) {     // test knob: both fp32 walk kernels give the same bits
+        const long v = strtol(env, nullptr, 10);
+        if (v == 1 || v == 2) e->walk_bodies_per_lane = (int)v;
+    }
     int rc = use_device(e);
     if (rc == NBE_OK && hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking) != hipSuccess) {
         nbe_set_error("hipStreamCreate failed");

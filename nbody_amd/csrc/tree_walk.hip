@@ -470,6 +470,144 @@ __global__ __launch_bounds__(WALK_BLOCK) void walk_group_kernel(
     }
 }
 
+// ---- per-body criterion, two bodies per lane (fp32) -----------------------------------------------------------
+// walk_kernel's rule and arithmetic, body for body (the same interactions in the same order, the same bits), with the
+// 128 Morton-consecutive bodies base + l and base + 64 + l in lane l behind ONE cursor.  The wave visits the union of
+// what its 128 bodies visit, 1.16 times the visits of a 64-body wave instead of twice, and the arithmetic of the two
+// bodies is packed (v_pk_add/fma/mul_f32): 16 vector instructions per visit for two bodies against 12 for one, and
+// half the node records, scalar instructions and waits per body.  It rests on the sleeping-lane scheme of walk_kernel
+// (a body that sits out carries +infinity as its floor under r^2, so nothing in the visit is per body but the
+// arithmetic itself); with the per-body tests and selects of the earlier visit, two bodies per lane were slower
+// (2.57 against 2.08 ms at 1M bodies).
+template <int OUT, bool COUNT>
+__global__ __launch_bounds__(WALK_BLOCK) void walk_pair_kernel(
+    const NodeF* __restrict__ nodes, const int* __restrict__ counters, const float4* __restrict__ posm, int t0, int t1,
+    float floor2, float G, float dt, float4* __restrict__ acc_out, const float4* __restrict__ pos_in,
+    const float4* __restrict__ vel_in, float4* __restrict__ pos_out, float4* __restrict__ vel_out,
+    unsigned long long* __restrict__ interactions, const uint32_t* __restrict__ tail_orig, unsigned tail_limit)
+{
+    typedef float R2 __attribute__((ext_vector_type(2)));
+    const int na = counters[0];
+    const int total = counters[1];
+    const int tend = t1 < na ? t1 : na;
+    // same XCD-aware placement as walk_kernel: the workgroups of one XCD own a contiguous eighth of the bodies
+    const unsigned nwg = gridDim.x, q8 = nwg / 8, r8 = nwg % 8, xcd = blockIdx.x % 8;
+    const unsigned wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + blockIdx.x / 8;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int idx[2];
+    idx[0] = t0 + (int)wg * (2 * WALK_BLOCK) + wave * 128 + lane;
+    idx[1] = idx[0] + 64;
+    bool valid[2];
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const int i = idx[k];
+        if (OUT == OUT_FUSED && i >= tend && i < t1) {     // bodies removed by the bound check move on unchanged
+            pos_out[i] = pos_in[i];
+            vel_out[i] = vel_in[i];
+        }
+        valid[k] = i < tend;
+    }
+    if (__ballot(valid[0] || valid[1]) == 0 || total <= 0) return;
+
+    R2 px = {0, 0}, py = {0, 0}, pz = {0, 0};
+    if (valid[0]) { const float4 p = posm[idx[0]]; px.x = p.x; py.x = p.y; pz.x = p.z; }
+    if (valid[1]) { const float4 p = posm[idx[1]]; px.y = p.x; py.y = p.y; pz.y = p.z; }
+    // (NBE_QUIRK_DROP_TAIL: bodies past tail_limit in upload order are not walked, as in walk_kernel)
+    const bool walked0 = valid[0] && !(tail_orig && tail_orig[idx[0]] >= tail_limit);
+    const bool walked1 = valid[1] && !(tail_orig && tail_orig[idx[1]] >= tail_limit);
+    int my_skip0 = walked0 ? 0 : 0x7fffffff, my_skip1 = walked1 ? 0 : 0x7fffffff;
+    float floor2v = floor2;
+    asm volatile("" : "+v"(floor2v));
+    R2 seed = {walked0 ? floor2v : (float)INFINITY, walked1 ? floor2v : (float)INFINITY};
+    int next_wake = 0x7fffffff, sp = 0, ends = 0;
+    R2 fx = {0, 0}, fy = {0, 0}, fz = {0, 0};
+    float phi[2] = {0, 0};
+    // Everything the epilogue needs from the kernel arguments is fetched here, ahead of the loop: a scalar load that
+    // the compiler places at the loop's exit could be given the registers of the node request that is still in flight
+    asm volatile("" :: "s"(G), "s"(dt), "s"(acc_out), "s"(interactions));
+    unsigned count = 0;
+    int cur = 0;
+    auto visit = [&](auto& here, auto& there) -> bool {
+        const auto nd = arrived(here);
+        const int skip = nd.skip;
+        asm volatile("" : "+s"(cur));             // (keeps the compare behind the wait, as in walk_kernel)
+        if (cur == next_wake) {                   // the cursor leaves the innermost cell in which bodies sleep
+            if (my_skip0 <= cur) seed.x = floor2v;
+            if (my_skip1 <= cur) seed.y = floor2v;
+            --sp;
+            next_wake = __builtin_amdgcn_readlane(ends, sp);
+        }
+        const float nx = as_real(nd.x), ny = as_real(nd.y), nz = as_real(nd.z);
+        const R2 dx = R2{nx, nx} - px, dy = R2{ny, ny} - py, dz = R2{nz, nz} - pz;
+        R2 r2 = __builtin_elementwise_fma(dx, dx, __builtin_elementwise_fma(dy, dy, __builtin_elementwise_fma(dz, dz, seed)));
+        const float w2 = as_real(nd.w2);
+        const bool open0 = r2.x < w2, open1 = r2.y < w2;
+        // (two ballots joined by a scalar OR: the ballot of "open0 || open1" goes through a vector register)
+        const unsigned long long opening = __builtin_amdgcn_ballot_w64(open0) | __builtin_amdgcn_ballot_w64(open1);
+        const int next = opening != 0 ? cur + 1 : skip;
+        float keep = r2.x;
+        there = request_raw(nodes, next, keep);    // the force arithmetic below runs while this is in flight
+        r2.x = keep;
+        const float mass = as_real(nd.m);
+        bool u0 = false, u1 = false;
+        if (COUNT) {
+            u0 = !open0 && r2.x < (float)INFINITY && (dx.x != 0.0f || dy.x != 0.0f || dz.x != 0.0f);
+            u1 = !open1 && r2.y < (float)INFINITY && (dx.y != 0.0f || dy.y != 0.0f || dz.y != 0.0f);
+        }
+        if (opening != 0) {
+            // the cursor descends: the bodies that accept the cell sleep until the cursor reaches its end
+            const bool rest0 = !open0 && r2.x < (float)INFINITY, rest1 = !open1 && r2.y < (float)INFINITY;
+            if ((__builtin_amdgcn_ballot_w64(rest0) | __builtin_amdgcn_ballot_w64(rest1)) != 0) {
+                if (rest0) { my_skip0 = skip; seed.x = (float)INFINITY; }
+                if (rest1) { my_skip1 = skip; seed.y = (float)INFINITY; }
+                if (skip != next_wake) {
+                    if (lane == sp) ends = next_wake;
+                    ++sp;
+                    next_wake = skip;
+                }
+            }
+            // a body that opens the cell takes nothing from it: an infinite distance gives it the weight 0
+            if (open0) r2.x = (float)INFINITY;
+            if (open1) r2.y = (float)INFINITY;
+        }
+        const R2 rinv = {rsq_dev(r2.x), rsq_dev(r2.y)};
+        const R2 w = (rinv * rinv) * (rinv * R2{mass, mass});
+        fx = __builtin_elementwise_fma(dx, w, fx);
+        fy = __builtin_elementwise_fma(dy, w, fy);
+        fz = __builtin_elementwise_fma(dz, w, fz);
+        if (COUNT) {
+            count += (unsigned)__popcll(__builtin_amdgcn_ballot_w64(u0)) + (unsigned)__popcll(__builtin_amdgcn_ballot_w64(u1));
+            if (u0) phi[0] += rinv.x * mass;
+            if (u1) phi[1] += rinv.y * mass;
+        }
+        cur = next;
+        return next < total;
+    };
+    float none = 0;
+    auto slot_a = request_raw(nodes, 0, none);
+    decltype(slot_a) slot_b;
+    for (;;) {
+        if (!visit(slot_a, slot_b)) break;
+        if (!visit(slot_b, slot_a)) break;
+    }
+    settle(slot_a, slot_b);      // the record requested last is never read, but has to land before its registers are reused
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+    if (COUNT && lane == 0 && interactions) atomicAdd(interactions, (unsigned long long)count);
+    const float fxs[2] = {fx.x, fx.y}, fys[2] = {fy.x, fy.y}, fzs[2] = {fz.x, fz.y};
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        if (!valid[k]) continue;
+        const int i = idx[k];
+        if (OUT == OUT_ACC) {
+            float4 o; o.x = G * fxs[k]; o.y = G * fys[k]; o.z = G * fzs[k]; o.w = phi[k];
+            acc_out[i] = o;
+        } else {
+            kick_drift<float>(i, G * fxs[k], G * fys[k], G * fzs[k], dt, pos_in, vel_in, pos_out, vel_out, (float4*)nullptr);
+        }
+    }
+}
+
 #define WALK_LAUNCH(...)                                                                                     \
     hipLaunchKernelGGL((soft ? walk_kernel<R, A, NodeT, __VA_ARGS__, true> : walk_kernel<R, A, NodeT, __VA_ARGS__, false>),
 
@@ -514,6 +652,32 @@ static int launch_walk(nbe_engine* e, const void* src, uint64_t t0, uint64_t t1,
 #undef GROUP_LAUNCH
         NBE_HIP(hipGetLastError());
         return NBE_OK;
+    }
+    if constexpr (__is_same(R, float) && __is_same(A, float)) {
+        // fp32: two bodies per lane where there are enough bodies to fill the GPU several times over with 128-body waves
+        // (measured, pair against one body per lane: 1M bodies 1.83 / 1.78 ms, 2M 3.46 / 3.49, 3M 4.89 / 5.16, 4M 6.53 /
+        // 7.35, 8M 13.1 / 15.5, 16M 26.3 / 31.8: one million bodies are exactly one fill, and the slowest wave then sets
+        // the time).  The results are the same bits either way; NBODY_WALK_BODIES_PER_LANE=1 or 2 forces the choice (tests).
+        const int forced = e->walk_bodies_per_lane;
+        const bool pair = forced == 2 || (forced != 1 && nt >= 3u * (1u << 20));
+        if (pair) {
+            dim3 pgrid(cdiv(nt, 2 * WALK_BLOCK));
+#define PAIR_LAUNCH(...)                                                                                                       \
+    hipLaunchKernelGGL((walk_pair_kernel<__VA_ARGS__>), pgrid, dim3(WALK_BLOCK), 0, e->stream, (const NodeF*)e->tw.nodes,      \
+                       e->tw.counters, (const float4*)src, (int)t0, (int)t1, floor2, G, dt, (float4*)e->acc, pos_in, vel_in, \
+                       pos_out, vel_out, e->tw.d_interactions, tail_orig, tail_limit)
+            if (fused) {
+                PAIR_LAUNCH(OUT_FUSED, false);
+            } else if (count) {
+                NBE_HIP(hipMemsetAsync(e->tw.d_interactions, 0, 8 * sizeof(unsigned long long), e->stream));
+                PAIR_LAUNCH(OUT_ACC, true);
+            } else {
+                PAIR_LAUNCH(OUT_ACC, false);
+            }
+#undef PAIR_LAUNCH
+            NBE_HIP(hipGetLastError());
+            return NBE_OK;
+        }
     }
     dim3 grid(cdiv(nt, WALK_BLOCK));
     if (fused) {

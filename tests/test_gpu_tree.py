@@ -333,3 +333,32 @@ def test_16m_plummer_on_one_gpu(gpu):
     ref = np.concatenate([O.direct_rows(mass, pos, t0=int(t), t1=int(t) + 1) for t in sample]) / mass[sample][:, None]
     er = relerr(acc[sample], ref)
     assert np.median(er) <= 1e-2 and er.max() <= 8e-2
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 127, 128, 129, 1000, 8191, 8192, 8193, 50001, 300000])
+def test_walk_with_two_bodies_per_lane_equals_one_body_per_lane(gpu, monkeypatch, n):
+    """The fp32 walk has two kernels for the same rule: one body per lane and, for large scenes, two bodies per lane
+    behind one cursor (NBODY_WALK_BODIES_PER_LANE forces either).  Every body must get the same interactions in the same
+    order: accelerations, interaction counts and stepped states equal bit for bit, also with bodies outside the bound,
+    coincident bodies, the reference's unwalked tail and ragged sizes."""
+    rng = np.random.default_rng(n)
+    b = physics.plummer(n, seed=n % 7, a=2e3)
+    pos = b.pos.copy()
+    if n > 10:
+        pos[3] = pos[7]                      # a bucket of equal keys
+        pos[5] = [4e4, 0, 0]                 # outside the bound
+    out = []
+    for knob in ("1", "2"):
+        monkeypatch.setenv("NBODY_WALK_BODIES_PER_LANE", knob)
+        res = []
+        for kw in (dict(), dict(drop_tail=True), dict(eps=3.0, theta=0.3)):
+            with Engine(mode="tree", precision="f32", **({"theta": 0.6} | kw)) as e:
+                e.upload(pos, b.vel, b.mass)
+                acc, alive = e.accel()
+                st = e.stats()
+                e.step(3)
+                res.append((acc, alive, np.array([st.interactions]), *e.download()))
+        out.append(res)
+    for ra, rb in zip(out[0], out[1]):
+        for a, c in zip(ra, rb):
+            assert np.array_equal(a, c, equal_nan=True)
