@@ -65,6 +65,18 @@ __device__ __forceinline__ void settle(PendingF& p, PendingF& q) { asm volatile(
 __device__ __forceinline__ void settle(PendingD&, PendingD&) {}
 __device__ __forceinline__ void settle(PendingF& p) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(p.v)); }
 __device__ __forceinline__ void settle(PendingD&) {}
+// A second form of the wait, for the kernel in which the register allocator answered the first with copies ahead of the
+// wait (two bodies per lane in mixed precision: it gave the value in flight and the value arrived different registers,
+// and a tied operand is satisfied by a copy).  Here the record is a plain input that is never redefined, and the wait is
+// tied to the bodies' coordinates instead: everything that consumes the record combines it with the coordinates or is
+// decided by such a value, so it stays behind the wait.  (Used everywhere it measured 1-3 % slower in the fp32 kernels.)
+template <typename P>
+__device__ __forceinline__ RawF arrived_behind(PendingF& p, P& x, P& y, P& z)
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x), "+v"(y), "+v"(z) : "s"(p.v));
+    return RawF{p.v[0], p.v[1], p.v[2], p.v[3], p.v[4], (int)p.v[5]};
+}
+__device__ __forceinline__ void settle_plain(PendingF& p) { asm volatile("s_waitcnt lgkmcnt(0)" :: "s"(p.v)); }
 __device__ __forceinline__ PendingD request_raw(const NodeD* __restrict__ nodes, int i, double&) { return PendingD{load_raw(nodes, i)}; }
 __device__ __forceinline__ RawD arrived(PendingD& p) { return p.r; }
 
@@ -479,14 +491,19 @@ __global__ __launch_bounds__(WALK_BLOCK) void walk_group_kernel(
 // (a body that sits out carries +infinity as its floor under r^2, so nothing in the visit is per body but the
 // arithmetic itself); with the per-body tests and selects of the earlier visit, two bodies per lane were slower
 // (2.57 against 2.08 ms at 1M bodies).
-template <int OUT, bool COUNT>
+// A = double (mixed precision): the fp32 partial sums of both bodies join fp64 totals every 64 visits, as in walk_kernel;
+// the totals live in LDS, and positions are read from the fp32 mirror while the fp64 state is integrated.
+template <typename A, int OUT, bool COUNT>
 __global__ __launch_bounds__(WALK_BLOCK) void walk_pair_kernel(
     const NodeF* __restrict__ nodes, const int* __restrict__ counters, const float4* __restrict__ posm, int t0, int t1,
-    float floor2, float G, float dt, float4* __restrict__ acc_out, const float4* __restrict__ pos_in,
-    const float4* __restrict__ vel_in, float4* __restrict__ pos_out, float4* __restrict__ vel_out,
+    float floor2, A G, A dt, typename V4<A>::type* __restrict__ acc_out, const typename V4<A>::type* __restrict__ pos_in,
+    const typename V4<A>::type* __restrict__ vel_in, typename V4<A>::type* __restrict__ pos_out,
+    typename V4<A>::type* __restrict__ vel_out, float4* __restrict__ mirror_out,
     unsigned long long* __restrict__ interactions, const uint32_t* __restrict__ tail_orig, unsigned tail_limit)
 {
     typedef float R2 __attribute__((ext_vector_type(2)));
+    using A4 = typename V4<A>::type;
+    constexpr bool BLOCKED = !__is_same(A, float);
     const int na = counters[0];
     const int total = counters[1];
     const int tend = t1 < na ? t1 : na;
@@ -504,6 +521,7 @@ __global__ __launch_bounds__(WALK_BLOCK) void walk_pair_kernel(
         if (OUT == OUT_FUSED && i >= tend && i < t1) {     // bodies removed by the bound check move on unchanged
             pos_out[i] = pos_in[i];
             vel_out[i] = vel_in[i];
+            if (mirror_out) { const A4 p = pos_in[i]; mirror_out[i] = make_float4((float)p.x, (float)p.y, (float)p.z, (float)p.w); }
         }
         valid[k] = i < tend;
     }
@@ -521,14 +539,20 @@ __global__ __launch_bounds__(WALK_BLOCK) void walk_pair_kernel(
     R2 seed = {walked0 ? floor2v : (float)INFINITY, walked1 ? floor2v : (float)INFINITY};
     int next_wake = 0x7fffffff, sp = 0, ends = 0;
     R2 fx = {0, 0}, fy = {0, 0}, fz = {0, 0};
-    float phi[2] = {0, 0};
+    A phi[2] = {0, 0};
+    __shared__ A tot[BLOCKED ? 6 : 1][BLOCKED ? WALK_BLOCK : 1];
+    if constexpr (BLOCKED) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) tot[k][threadIdx.x] = 0;
+    }
+    int it = 0;
     // Everything the epilogue needs from the kernel arguments is fetched here, ahead of the loop: a scalar load that
     // the compiler places at the loop's exit could be given the registers of the node request that is still in flight
     asm volatile("" :: "s"(G), "s"(dt), "s"(acc_out), "s"(interactions));
     unsigned count = 0;
     int cur = 0;
     auto visit = [&](auto& here, auto& there) -> bool {
-        const auto nd = arrived(here);
+        const auto nd = BLOCKED ? arrived_behind(here, px, py, pz) : arrived(here);
         const int skip = nd.skip;
         asm volatile("" : "+s"(cur));             // (keeps the compare behind the wait, as in walk_kernel)
         if (cur == next_wake) {                   // the cursor leaves the innermost cell in which bodies sleep
@@ -577,11 +601,22 @@ __global__ __launch_bounds__(WALK_BLOCK) void walk_pair_kernel(
         fz = __builtin_elementwise_fma(dz, w, fz);
         if (COUNT) {
             count += (unsigned)__popcll(__builtin_amdgcn_ballot_w64(u0)) + (unsigned)__popcll(__builtin_amdgcn_ballot_w64(u1));
-            if (u0) phi[0] += rinv.x * mass;
-            if (u1) phi[1] += rinv.y * mass;
+            const R2 pm = rinv * R2{mass, mass};
+            phi[0] += u0 ? (A)pm.x : (A)0;
+            phi[1] += u1 ? (A)pm.y : (A)0;
+        }
+        if constexpr (BLOCKED) if ((++it & 63) == 0) {
+            tot[0][threadIdx.x] += (A)fx.x; tot[1][threadIdx.x] += (A)fy.x; tot[2][threadIdx.x] += (A)fz.x;
+            tot[3][threadIdx.x] += (A)fx.y; tot[4][threadIdx.x] += (A)fy.y; tot[5][threadIdx.x] += (A)fz.y;
+            fx = R2{0, 0}; fy = R2{0, 0}; fz = R2{0, 0};
         }
         cur = next;
-        return next < total;
+        if constexpr (!BLOCKED) return next < total;
+        // (mixed precision waits on its way out of the visit, as walk_kernel does: with the wait behind the loop the two
+        // ways out have to agree on the registers of both slots, and the compiler copies one while it is in flight)
+        if (next < total) return true;
+        settle_plain(there);
+        return false;
     };
     float none = 0;
     auto slot_a = request_raw(nodes, 0, none);
@@ -590,7 +625,8 @@ __global__ __launch_bounds__(WALK_BLOCK) void walk_pair_kernel(
         if (!visit(slot_a, slot_b)) break;
         if (!visit(slot_b, slot_a)) break;
     }
-    settle(slot_a, slot_b);      // the record requested last is never read, but has to land before its registers are reused
+    // The record requested last is never read, but has to land before its registers are reused.
+    if constexpr (!BLOCKED) settle(slot_a, slot_b);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
     if (COUNT && lane == 0 && interactions) atomicAdd(interactions, (unsigned long long)count);
@@ -599,11 +635,13 @@ __global__ __launch_bounds__(WALK_BLOCK) void walk_pair_kernel(
     for (int k = 0; k < 2; k++) {
         if (!valid[k]) continue;
         const int i = idx[k];
+        A sx = (A)fxs[k], sy = (A)fys[k], sz = (A)fzs[k];
+        if constexpr (BLOCKED) { sx += tot[3 * k][threadIdx.x]; sy += tot[3 * k + 1][threadIdx.x]; sz += tot[3 * k + 2][threadIdx.x]; }
         if (OUT == OUT_ACC) {
-            float4 o; o.x = G * fxs[k]; o.y = G * fys[k]; o.z = G * fzs[k]; o.w = phi[k];
+            A4 o; o.x = G * sx; o.y = G * sy; o.z = G * sz; o.w = phi[k];
             acc_out[i] = o;
         } else {
-            kick_drift<float>(i, G * fxs[k], G * fys[k], G * fzs[k], dt, pos_in, vel_in, pos_out, vel_out, (float4*)nullptr);
+            kick_drift<A>(i, G * sx, G * sy, G * sz, dt, pos_in, vel_in, pos_out, vel_out, mirror_out);
         }
     }
 }
@@ -653,24 +691,31 @@ static int launch_walk(nbe_engine* e, const void* src, uint64_t t0, uint64_t t1,
         NBE_HIP(hipGetLastError());
         return NBE_OK;
     }
-    if constexpr (__is_same(R, float) && __is_same(A, float)) {
-        // fp32: two bodies per lane where there are enough bodies to fill the GPU several times over with 128-body waves
+    if constexpr (__is_same(R, float)) {
+        // fp32 visits: two bodies per lane where there are enough bodies to fill the GPU several times over with 128-body waves
         // (measured, pair against one body per lane: 1M bodies 1.83 / 1.78 ms, 2M 3.46 / 3.49, 3M 4.89 / 5.16, 4M 6.53 /
         // 7.35, 8M 13.1 / 15.5, 16M 26.3 / 31.8: one million bodies are exactly one fill, and the slowest wave then sets
-        // the time).  The results are the same bits either way; NBODY_WALK_BODIES_PER_LANE=1 or 2 forces the choice (tests).
+        // the time).  fp32 sums are the same bits either way, so the launch's own size decides; mixed precision rounds by
+        // wavefront (its fp32 partial sums join the fp64 totals every 64 visits of the wavefront), so there the size of the
+        // scene decides, which every shard of a scene shares.  NBODY_WALK_BODIES_PER_LANE=1 or 2 forces the choice (tests).
         const int forced = e->walk_bodies_per_lane;
-        const bool pair = forced == 2 || (forced != 1 && nt >= 3u * (1u << 20));
+        const size_t deciding = __is_same(A, float) ? nt : (size_t)e->n;
+        // (the instrumented pass in mixed precision stays with one body per lane: the compiler rejects that variant of
+        // the pair kernel, "illegal VGPR to SGPR copy"; its sums then differ from the step's by the rounding of the blocks)
+        const bool pair = (forced == 2 || (forced != 1 && deciding >= 3u * (1u << 20))) && !(count && !__is_same(A, float));
         if (pair) {
             dim3 pgrid(cdiv(nt, 2 * WALK_BLOCK));
 #define PAIR_LAUNCH(...)                                                                                                       \
-    hipLaunchKernelGGL((walk_pair_kernel<__VA_ARGS__>), pgrid, dim3(WALK_BLOCK), 0, e->stream, (const NodeF*)e->tw.nodes,      \
-                       e->tw.counters, (const float4*)src, (int)t0, (int)t1, floor2, G, dt, (float4*)e->acc, pos_in, vel_in, \
-                       pos_out, vel_out, e->tw.d_interactions, tail_orig, tail_limit)
+    hipLaunchKernelGGL((walk_pair_kernel<A, __VA_ARGS__>), pgrid, dim3(WALK_BLOCK), 0, e->stream, (const NodeF*)e->tw.nodes,   \
+                       e->tw.counters, (const float4*)src, (int)t0, (int)t1, floor2, G, dt, (A4*)e->acc, pos_in, vel_in,       \
+                       pos_out, vel_out, mirror_out, e->tw.d_interactions, tail_orig, tail_limit)
             if (fused) {
                 PAIR_LAUNCH(OUT_FUSED, false);
             } else if (count) {
-                NBE_HIP(hipMemsetAsync(e->tw.d_interactions, 0, 8 * sizeof(unsigned long long), e->stream));
-                PAIR_LAUNCH(OUT_ACC, true);
+                if constexpr (__is_same(A, float)) {
+                    NBE_HIP(hipMemsetAsync(e->tw.d_interactions, 0, 8 * sizeof(unsigned long long), e->stream));
+                    PAIR_LAUNCH(OUT_ACC, true);
+                }
             } else {
                 PAIR_LAUNCH(OUT_ACC, false);
             }

@@ -362,3 +362,34 @@ def test_walk_with_two_bodies_per_lane_equals_one_body_per_lane(gpu, monkeypatch
     for ra, rb in zip(out[0], out[1]):
         for a, c in zip(ra, rb):
             assert np.array_equal(a, c, equal_nan=True)
+
+
+@pytest.mark.parametrize("n", [2, 65, 129, 1000, 8193, 50001, 300000])
+def test_mixed_walk_with_two_bodies_per_lane_agrees_with_one_body_per_lane(gpu, monkeypatch, n):
+    """Mixed precision has the same two kernels.  Its fp32 partial sums join the fp64 totals every 64 visits of the
+    wavefront, and a wavefront of 128 bodies visits other nodes than one of 64, so the two round differently: the
+    accelerations agree to 2e-6 of each body's acceleration (fp32 rounding of a block sum is 6e-8 per term), the same
+    bodies survive, and both stay within the fp32 tolerances against the CPU restatement (median 1e-6, p99.9 1e-3)."""
+    b = physics.plummer(n, seed=n % 5, a=2e3)
+    pos = b.pos.copy()
+    if n > 10:
+        pos[3] = pos[7]
+        pos[5] = [4e4, 0, 0]
+    res = []
+    for knob in ("1", "2"):
+        monkeypatch.setenv("NBODY_WALK_BODIES_PER_LANE", knob)
+        with Engine(mode="tree", precision="mixed", theta=0.6, eps=2.0) as e:
+            e.upload(pos, b.vel, b.mass)
+            e.step(3)                         # fused steps take the kernel the knob names
+            p, v, m, ids = e.download()
+            acc, alive = e.accel()            # (the instrumented pass always walks one body per lane)
+            res.append((p, v, m, ids, acc, alive))
+    p1, v1, m1, id1, acc1, al1 = res[0]
+    p2, v2, m2, id2, acc2, al2 = res[1]
+    assert np.array_equal(id1, id2) and np.array_equal(m1, m2) and np.array_equal(al1, al2)
+    dv = np.linalg.norm(v1 - v2, axis=1)
+    # three kicks of dt = 3600 s: the velocity difference is dt times the difference of the accelerations
+    amag = np.linalg.norm(acc1[al1.astype(bool)], axis=1) if al1.dtype != bool else np.linalg.norm(acc1[al1], axis=1)
+    scale = 3 * 3600.0 * np.maximum(np.median(amag), 1e-300)
+    assert dv.max() <= 2e-5 * scale * max(1.0, amag.max() / np.median(amag)), (dv.max(), scale)
+    assert np.abs(p1 - p2).max() <= 1e-6 * np.abs(p1).max()
