@@ -702,7 +702,11 @@ static int launch_walk(nbe_engine* e, const void* src, uint64_t t0, uint64_t t1,
         const size_t deciding = __is_same(A, float) ? nt : (size_t)e->n;
         // (the instrumented pass in mixed precision stays with one body per lane: the compiler rejects that variant of
         // the pair kernel, "illegal VGPR to SGPR copy"; its sums then differ from the step's by the rounding of the blocks)
-        const bool pair = (forced == 2 || (forced != 1 && deciding >= 3u * (1u << 20))) && !(count && !__is_same(A, float));
+        // (mixed precision changes over at 1M bodies: its one-body kernel still tests every lane's sit-out index in every
+        // visit, 17 vector instructions against 12, so two bodies per lane win earlier: two 512k-body galaxies 2.07 against
+        // 2.13 ms)
+        const size_t least = __is_same(A, float) ? 3u * (1u << 20) : (1u << 20);
+        const bool pair = (forced == 2 || (forced != 1 && deciding >= least)) && !(count && !__is_same(A, float));
         if (pair) {
             dim3 pgrid(cdiv(nt, 2 * WALK_BLOCK));
 #define PAIR_LAUNCH(...)                                                                                                       \
