@@ -82,6 +82,35 @@ if agg:
         if os.path.exists(log):
             f.write("\n# " + "# ".join(l for l in open(log) if l.startswith("phase")))
 
+# ---- the two 16M-body workloads (benchmark configurations 4 and 5): kernels by precision ----
+agg = defaultdict(lambda: [0, 0.0, 1e30, 0.0])
+for r in rows("trace_walk16/**/*kernel_trace.csv"):
+    d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+    full = r["Kernel_Name"].replace("void ", "")
+    name = full.split("(")[0].split("<")[0]
+    if name.startswith("walk"):
+        args = [a.strip() for a in full.split("(")[0].split("<", 1)[1].rstrip(">").split(",")]
+        if name == "walk_pair_kernel":      # <A, OUT, COUNT>
+            prec, counting = ("mixed" if args[0] == "double" else "f32"), args[2] == "true"
+        else:                               # <R, A, NodeT, OUT, COUNT, SOFT>
+            prec = "f64" if args[0] == "double" else "mixed" if args[1] == "double" else "f32"
+            counting = args[4] == "true"
+        name += f"<{prec}>" + (" instrumented" if counting else "")
+    a = agg[name]
+    a[0] += 1; a[1] += d; a[2] = min(a[2], d); a[3] = max(a[3], d)
+if agg:
+    with open(os.path.join(root, "profiles", f"{tag}_walk_16M_kernel_stats.txt"), "w") as f:
+        total = sum(a[1] for a in agg.values())
+        f.write(f"# rocprofv3 --kernel-trace --stats -- python3 profiles/walk_16M.py   (tag {tag})\n"
+                f"# 16,777,216 bodies, theta 0.5, six steps each of the fp32 Plummer sphere and of the two 8M-body galaxies in mixed\n"
+                f"# precision (eps = 1 m); both walk two bodies per lane\n")
+        f.write(f"{'kernel':32s} {'calls':>7s} {'total_us':>14s} {'avg_us':>12s} {'min_us':>12s} {'max_us':>12s} {'share':>7s}\n")
+        for k, a in sorted(agg.items(), key=lambda kv: -kv[1][1])[:24]:
+            f.write(f"{k:32s} {a[0]:7d} {a[1]:14.1f} {a[1] / a[0]:12.2f} {a[2]:12.2f} {a[3]:12.2f} {100 * a[1] / total:6.2f}%\n")
+        log = os.path.join(base, "walk_16M.log")
+        if os.path.exists(log):
+            f.write("\n# " + "# ".join(l for l in open(log) if "walk" in l))
+
 # ---- counters ----
 pmc = defaultdict(lambda: defaultdict(lambda: [0, 0.0]))
 for sub in ("pmc_fetch_direct", "pmc_write_direct", "pmc_fetch_tree", "pmc_write_tree", "pmc_sq_direct", "pmc_sq_tree",
