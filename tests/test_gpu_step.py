@@ -363,3 +363,22 @@ def test_tree_body_limit():
         with pytest.raises(EngineError, match="2\\^26"):
             e.upload(z3, z3, z1)
         assert e.stats().n == 0
+
+
+@pytest.mark.parametrize("precision", ["f32", "mixed"])
+def test_shards_walking_two_bodies_per_lane_equal_one_engine(gpu, monkeypatch, precision):
+    """The walk with two bodies per lane (large scenes; forced here) on three shards behind one handle: ranges start at
+    multiples of 256 bodies, so a wavefront holds the same 128 bodies as on one engine and mixed precision, which rounds
+    by wavefront, equals the one-engine run bit for bit too."""
+    monkeypatch.setenv("NBODY_WALK_BODIES_PER_LANE", "2")
+    b = physics.plummer(30011, seed=4, a=2e3)
+    with Engine(mode="tree", precision=precision, theta=0.6, eps=1.0) as one:
+        one.upload(b.pos, b.vel, b.mass)
+        one.step(4)
+        want = one.download()
+    with Engine(mode="tree", precision=precision, theta=0.6, eps=1.0, devices=[0, 0, 0]) as e:
+        e.upload(b.pos, b.vel, b.mass)
+        e.step(4)
+        got = e.download()
+    for a, w in zip(got, want):
+        assert np.array_equal(a, w)
