@@ -80,6 +80,15 @@ __device__ __forceinline__ void settle_plain(PendingF& p) { asm volatile("s_wait
 __device__ __forceinline__ PendingD request_raw(const NodeD* __restrict__ nodes, int i, double&) { return PendingD{load_raw(nodes, i)}; }
 __device__ __forceinline__ RawD arrived(PendingD& p) { return p.r; }
 
+// v[lane] = value for a wave-uniform value and lane number, both in scalar registers produced by scalar instructions (a
+// lane number written by a vector instruction would need four wait states in front of this one).
+__device__ __forceinline__ void write_lane(int& v, int value, int lane)
+{
+    // (one scalar register per vector instruction on this chip: the lane number goes through M0, which the compiler
+    // reserves and sets itself in front of any instruction of its own that reads it; none in this file does)
+    asm("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(v) : "s"(value), "s"(lane));
+}
+
 __device__ __forceinline__ RawF pick(bool c, const RawF& a, const RawF& b)
 {
     return RawF{c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z, c ? a.m : b.m, c ? a.w2 : b.w2, c ? a.skip : b.skip};
@@ -270,14 +279,17 @@ __global__ __launch_bounds__(WALK_BLOCK) void walk_kernel(
         if (!EVENTS && take) my_skip = skip;
         if (EVENTS && opening != 0) {
             // the cursor descends: the lanes that accept the cell sleep until the cursor reaches its end
-            const bool rest = !open && r2 < (R)INFINITY;
-            if (__builtin_amdgcn_ballot_w64(rest) != 0) {
+            const bool fin = r2 < (R)INFINITY;
+            const bool rest = !open && fin;
+            // (the vote on "somebody rests" from the masks of the plain compares: the ballot of a combined condition goes
+            // through a vector register and back)
+            if ((__builtin_amdgcn_ballot_w64(fin) & ~opening) != 0) {
                 if (rest) { my_skip = skip; seed = (R)INFINITY; }
-                if (skip != next_wake) {           // (a last child ends where its parent ends: one wake for both)
-                    if ((int)(threadIdx.x & 63u) == sp) ends = next_wake;
-                    ++sp;
-                    next_wake = skip;
-                }
+                // push the end of the cell around this one (a last child ends where its parent ends: one wake for both,
+                // nothing pushed; the write below is then overwritten by the next push)
+                write_lane(ends, next_wake, sp);
+                sp += skip != next_wake;
+                next_wake = skip;
             }
             // a lane that opens the cell takes nothing from it: an infinite distance gives it the weight 0
             if (open) r2 = (R)INFINITY;
@@ -580,11 +592,15 @@ __global__ __launch_bounds__(WALK_BLOCK) void walk_pair_kernel(
         }
         if (opening != 0) {
             // the cursor descends: the bodies that accept the cell sleep until the cursor reaches its end
-            const bool rest0 = !open0 && r2.x < (float)INFINITY, rest1 = !open1 && r2.y < (float)INFINITY;
+            const bool fin0 = r2.x < (float)INFINITY, fin1 = r2.y < (float)INFINITY;
+            const bool rest0 = !open0 && fin0, rest1 = !open1 && fin1;
+            // (taking this vote from the masks of the plain compares, as walk_kernel does, measured 0.5 % slower here)
             if ((__builtin_amdgcn_ballot_w64(rest0) | __builtin_amdgcn_ballot_w64(rest1)) != 0) {
                 if (rest0) { my_skip0 = skip; seed.x = (float)INFINITY; }
                 if (rest1) { my_skip1 = skip; seed.y = (float)INFINITY; }
+                // push the end of the cell around this one (a last child ends where its parent ends: one wake for both)
                 if (skip != next_wake) {
+                    // (v_writelane_b32, as in walk_kernel, does not compile here: "illegal VGPR to SGPR copy")
                     if (lane == sp) ends = next_wake;
                     ++sp;
                     next_wake = skip;
