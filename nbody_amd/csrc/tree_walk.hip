@@ -106,15 +106,20 @@ __device__ __forceinline__ double as_real(unsigned long long v) { return __longl
 __device__ __forceinline__ bool node_opens(const RawF& nd, float r2, float) { return r2 < as_real(nd.w2); }
 // The fp64 expression costs a square root and a division (about half of the visit's instructions), and its verdict
 // is that of  edge^2 > theta^2 * r^2  unless the two sides agree to within the rounding of either form.  So the
-// products decide, and only when some lane of the wave finds them closer than 1e-13 relative (a few hundred times the
-// combined rounding error of both forms), or r^2 is not positive, does the wave evaluate the reference's expression.
+// products decide, and only when some lane of the wave finds them within 1024 units in the last place of each other
+// (2.3e-13 relative, a few hundred times the combined rounding error of both forms) does the wave evaluate the
+// reference's expression.  Both sides are non-negative, so their distance in units in the last place is the distance of
+// their bit patterns, taken with integer instructions at twice the rate of the fp64 ones (a relative test in floating
+// point took six fp64 instructions here).  A lane that sits out carries r^2 = infinity: its pattern is far from any
+// finite edge^2 and the verdict "closed" is certain; r^2 = 0 against a leaf's edge 0 is within the window and goes the
+// reference's way (0 / 0 > theta is false).
 __device__ __forceinline__ bool node_opens(const RawD& nd, double r2, double theta)
 {
     const double w = as_real(nd.w);
     const double a = w * w, b = (theta * theta) * r2;
     bool open = a > b;
-    // (a lane that sits out carries r^2 = infinity: b is infinite and the verdict "closed" is certain)
-    const bool unsure = (fabs(a - b) <= 1e-13 * fmax(a, b) && b < (double)INFINITY) || !(r2 > 0.0);
+    const unsigned long long ia = (unsigned long long)__double_as_longlong(a), ib = (unsigned long long)__double_as_longlong(b);
+    const bool unsure = ia - ib + 1024ull <= 2048ull;
     if (__builtin_amdgcn_ballot_w64(unsure) != 0) open = w / sqrt(r2) > theta;
     return open;
 }
