@@ -80,6 +80,15 @@ __device__ __forceinline__ void settle_plain(PendingF& p) { asm volatile("s_wait
 __device__ __forceinline__ PendingD request_raw(const NodeD* __restrict__ nodes, int i, double&) { return PendingD{load_raw(nodes, i)}; }
 __device__ __forceinline__ RawD arrived(PendingD& p) { return p.r; }
 
+// min(x, 1e300) for an x that is never NaN (fmin would first quieten x with an instruction of its own)
+__device__ __forceinline__ double capped(double x)
+{
+    double c;
+    asm("v_min_f64 %0, %1, %2" : "=v"(c) : "v"(x), "v"(1e300));
+    return c;
+}
+__device__ __forceinline__ float capped(float x) { return x; }
+
 // v[lane] = value for a wave-uniform value and lane number, both in scalar registers produced by scalar instructions (a
 // lane number written by a vector instruction would need four wait states in front of this one).
 __device__ __forceinline__ void write_lane(int& v, int value, int lane)
@@ -104,6 +113,13 @@ __device__ __forceinline__ double as_real(unsigned long long v) { return __longl
 // compare, r^2 < edge^2/theta^2; fp64 nodes store the edge and repeat the reference's expression literally.
 // A leaf stores 0 and can never open.
 __device__ __forceinline__ bool node_opens(const RawF& nd, float r2, float) { return r2 < as_real(nd.w2); }
+// The same with the wave's vote (the mask of the lanes that open the node) beside the lane's own verdict.
+__device__ __forceinline__ bool node_opens(const RawF& nd, float r2, float, unsigned long long& opening)
+{
+    const bool open = r2 < as_real(nd.w2);
+    opening = __builtin_amdgcn_ballot_w64(open);
+    return open;
+}
 // The fp64 expression costs a square root and a division (about half of the visit's instructions), and its verdict
 // is that of  edge^2 > theta^2 * r^2  unless the two sides agree to within the rounding of either form.  So the
 // products decide, and only when some lane of the wave finds them within 1024 units in the last place of each other
@@ -121,6 +137,23 @@ __device__ __forceinline__ bool node_opens(const RawD& nd, double r2, double the
     const unsigned long long ia = (unsigned long long)__double_as_longlong(a), ib = (unsigned long long)__double_as_longlong(b);
     const bool unsure = ia - ib + 1024ull <= 2048ull;
     if (__builtin_amdgcn_ballot_w64(unsure) != 0) open = w / sqrt(r2) > theta;
+    return open;
+}
+// (the vote is taken from each compare where it stands: the ballot of the verdict after the two ways have joined goes
+// through a vector register and back)
+__device__ __forceinline__ bool node_opens(const RawD& nd, double r2, double theta, unsigned long long& opening)
+{
+    const double w = as_real(nd.w);
+    const double a = w * w, b = (theta * theta) * r2;
+    bool open = a > b;
+    opening = __builtin_amdgcn_ballot_w64(a > b);
+    const unsigned long long ia = (unsigned long long)__double_as_longlong(a), ib = (unsigned long long)__double_as_longlong(b);
+    const bool unsure = ia - ib + 1024ull <= 2048ull;
+    if (__builtin_amdgcn_ballot_w64(unsure) != 0) {
+        const double q = w / sqrt(r2);
+        open = q > theta;
+        opening = __builtin_amdgcn_ballot_w64(q > theta);
+    }
     return open;
 }
 
@@ -273,8 +306,8 @@ __global__ __launch_bounds__(WALK_BLOCK) void walk_kernel(
         // sleeping lanes have an infinite distance, so one compare is both the opening test and the vote
         const bool active = EVENTS || cur >= my_skip;
         const R rtest = active ? (SOFT ? r2 - floor2v : r2) : (R)INFINITY;
-        const bool open = node_opens(nd, rtest, theta);
-        const unsigned long long opening = __builtin_amdgcn_ballot_w64(open);
+        unsigned long long opening;
+        const bool open = node_opens(nd, rtest, theta, opening);
         const int next = opening != 0 ? cur + 1 : skip;
         there = request_raw(nodes, next, r2);      // the force arithmetic below runs while this is in flight
         const R mass = as_real(nd.m);
@@ -299,13 +332,14 @@ __global__ __launch_bounds__(WALK_BLOCK) void walk_kernel(
             // a lane that opens the cell takes nothing from it: an infinite distance gives it the weight 0
             if (open) r2 = (R)INFINITY;
         }
-        const R rinv = rsq_dev(r2);
+        // (fp64: the Newton step behind v_rsq_f64 turns rsq(inf) = 0 into NaN.  With events, infinity is capped at 1e300,
+        // whose weight 1e-450 * mass underflows to exactly 0: one instruction instead of a compare and two selects.)
+        const R rinv = rsq_dev(EVENTS && !__is_same(R, float) ? capped(r2) : r2);
         R rinv2 = rinv * rinv;
         // (keeps the compiler from pairing the two products in one packed multiply, for which it copies the mass
         // to a vector register: one more instruction that reads a scalar register)
         if (__is_same(R, float)) asm volatile("" : "+v"(rinv2));
-        // (fp64: the Newton step behind v_rsq_f64 turns rsq(inf) = 0 into NaN, so those lanes are masked by hand)
-        const bool none = !EVENTS ? !take : (!__is_same(R, float) && !(r2 < (R)INFINITY));
+        const bool none = !EVENTS && !take;      // (with events a lane that takes nothing has an infinite distance)
         const R w = none ? (R)0 : rinv2 * (rinv * mass);
         fx = fma(dx, w, fx);
         fy = fma(dy, w, fy);
