@@ -9,7 +9,7 @@ template<int MODE>
 __global__ __launch_bounds__(256) void k(float* out, int iters, float seed) {
   float a0=seed+threadIdx.x, a1=a0+1, a2=a0+2, a3=a0+3, a4=a0+4, a5=a0+5, a6=a0+6, a7=a0+7;
   float2_ p0={a0,a1}, p1={a2,a3}, p2={a4,a5}, p3={a6,a7}, p4={a1,a0}, p5={a3,a2}, p6={a5,a4}, p7={a7,a6};
-  float m = 0.999f; float2_ pm={0.999f,0.999f};
+  float m = 0.999f; float2_ pm={0.999f,0.999f}; float2_ spair={seed, seed*0.5f};
   for (int i=0;i<iters;i++) {
 #pragma unroll
     for (int u=0;u<8;u++) {
@@ -25,6 +25,12 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, float seed) {
       else if (MODE==7) { asm volatile("v_mul_f32 %0, %0, %0\n v_mul_f32 %1, %1, %1\n v_mul_f32 %2, %2, %2\n v_mul_f32 %3, %3, %3\n v_mul_f32 %4, %4, %4\n v_mul_f32 %5, %5, %5\n v_mul_f32 %6, %6, %6\n v_mul_f32 %7, %7, %7\n" ARGS8 ); }
       else if (MODE==8) { asm volatile("v_fma_f32 %0, %0, %0, %0\n v_fma_f32 %1, %1, %1, %1\n v_fma_f32 %2, %2, %2, %2\n v_fma_f32 %3, %3, %3, %3\n v_fma_f32 %4, %4, %4, %4\n v_fma_f32 %5, %5, %5, %5\n v_fma_f32 %6, %6, %6, %6\n v_fma_f32 %7, %7, %7, %7\n" ARGS8 ); }
       else if (MODE==9) { asm volatile("v_cmp_lt_f32 vcc, %0, %8\n v_cndmask_b32 %1, %1, %8, vcc\n v_cmp_lt_f32 vcc, %2, %8\n v_cndmask_b32 %3, %3, %8, vcc\n v_cmp_lt_f32 vcc, %4, %8\n v_cndmask_b32 %5, %5, %8, vcc\n v_cmp_lt_f32 vcc, %6, %8\n v_cndmask_b32 %7, %7, %8, vcc\n" ARGS8 : "v"(m) : "vcc"); }
+      else if (MODE==10) { asm volatile("v_pk_add_f32 %0, %8, %0 op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]\n v_pk_add_f32 %1, %8, %1 op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]\n v_pk_add_f32 %2, %8, %2 op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]\n v_pk_add_f32 %3, %8, %3 op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]\n v_pk_add_f32 %4, %8, %4 op_sel:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n v_pk_add_f32 %5, %8, %5 op_sel:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n v_pk_add_f32 %6, %8, %6 op_sel:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n v_pk_add_f32 %7, %8, %7 op_sel:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n" PARGS8 : "s"(spair)); }
+      else if (MODE==11) { asm volatile("v_pk_mul_f32 %0, %8, %0 op_sel_hi:[0,1]\n v_pk_mul_f32 %1, %8, %1 op_sel_hi:[0,1]\n v_pk_mul_f32 %2, %8, %2 op_sel_hi:[0,1]\n v_pk_mul_f32 %3, %8, %3 op_sel_hi:[0,1]\n v_pk_mul_f32 %4, %8, %4 op_sel_hi:[0,1]\n v_pk_mul_f32 %5, %8, %5 op_sel_hi:[0,1]\n v_pk_mul_f32 %6, %8, %6 op_sel_hi:[0,1]\n v_pk_mul_f32 %7, %8, %7 op_sel_hi:[0,1]\n" PARGS8 : "s"(spair)); }
+      else if (MODE==12) { asm volatile("v_cmp_gt_f32 s[20:21], %8, %0\n v_cmp_gt_f32 s[22:23], %8, %1\n v_cmp_gt_f32 s[20:21], %8, %2\n v_cmp_gt_f32 s[22:23], %8, %3\n v_cmp_gt_f32 s[20:21], %8, %4\n v_cmp_gt_f32 s[22:23], %8, %5\n v_cmp_gt_f32 s[20:21], %8, %6\n v_cmp_gt_f32 s[22:23], %8, %7\n" ARGS8 : "s"(seed) : "s20","s21","s22","s23"); }
+      else if (MODE==13) { asm volatile("v_min_f32 %0, %1, %0\n v_min_f32 %1, %2, %1\n v_min_f32 %2, %3, %2\n v_min_f32 %3, %4, %3\n v_min_f32 %4, %5, %4\n v_min_f32 %5, %6, %5\n v_min_f32 %6, %7, %6\n v_min_f32 %7, %0, %7\n" ARGS8 ); }
+      else if (MODE==14) { asm volatile("v_cmp_gt_f32 vcc, %8, %0\n v_cmp_gt_f32 vcc, %8, %1\n v_cmp_gt_f32 vcc, %8, %2\n v_cmp_gt_f32 vcc, %8, %3\n v_cmp_gt_f32 vcc, %8, %4\n v_cmp_gt_f32 vcc, %8, %5\n v_cmp_gt_f32 vcc, %8, %6\n v_cmp_gt_f32 vcc, %8, %7\n" ARGS8 : "v"(m) : "vcc"); }
+      else if (MODE==15) { asm volatile("v_rsq_f32 %0, %0\n v_pk_mul_f32 %1, %1, %1\n v_rsq_f32 %2, %2\n v_pk_mul_f32 %3, %3, %3\n v_rsq_f32 %4, %4\n v_pk_mul_f32 %5, %5, %5\n v_rsq_f32 %6, %6\n v_pk_mul_f32 %7, %7, %7\n" : "+v"(a0),"+v"(p1),"+v"(a2),"+v"(p3),"+v"(a4),"+v"(p5),"+v"(a6),"+v"(p7)); }
     }
   }
   float r = a0+a1+a2+a3+a4+a5+a6+a7 + p0.x+p1.x+p2.x+p3.x+p4.y+p5.y+p6.y+p7.y;
@@ -45,6 +51,7 @@ int main() {
   for (int w : {2,8}) {
     run<0>("v_mul_f32 vgpr (VOP2)", w); run<1>("v_add_f32 vgpr", w); run<2>("v_sub_f32 sgpr", w); run<3>("v_fma_f32 sgpr src1", w);
     run<4>("v_fmac_f32 vgpr", w); run<5>("v_pk_add_f32 neg", w); run<6>("v_pk_fma_f32 op_sel bcast", w); run<7>("v_mul_f32 a*a", w); run<8>("v_fma_f32 a*a+a", w); run<9>("v_cmp+v_cndmask pairs", w);
+    run<10>("v_pk_add_f32 sgpr pair", w); run<11>("v_pk_mul_f32 sgpr pair", w); run<12>("v_cmp_gt_f32 sgpr->sgpr", w); run<13>("v_min_f32 vgpr", w); run<14>("v_cmp_gt_f32 vgpr->vcc", w); run<15>("v_rsq_f32 + v_pk_mul alt", w);
   }
   return 0;
 }
