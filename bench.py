@@ -301,6 +301,33 @@ def main():
         extra["bh_theta0.5_fp32_plummer_16M_per_wave_criterion"] = {"steps_per_s": 5 / s3w, "ms_per_step": 1e3 * s3w / 5}
         e3w.close()
 
+    if not args.no_extra and (world > 1 or force_dist):
+        # benchmark configuration 5 on every GPU count above one: the two 8,388,608-body galaxies in mixed precision
+        # (fp32 pair terms, fp64 sums and integrator, eps = 1 m), targets sharded over the ranks, 100 fused steps with the
+        # drift it is judged by (every rank holds all bodies, so rank 0 sums the energies of its own copy)
+        gp = physics.galaxy_pair(1 << 23, seed=1)
+        e5 = Engine(mode="tree", precision="mixed", theta=0.5, eps=1.0, device=local)
+        e5.upload(gp.pos, gp.vel, gp.mass)
+        pscale = float((gp.mass * np.linalg.norm(gp.vel, axis=1)).sum())
+        del gp
+        ke0, pe0, p0 = e5.energy()
+        st5 = ShardedStepper(EngineShard(e5, device_index=local), always_gather=force_dist)
+        sec5 = timed_steps(st5.step, sync, barrier, 2, 98)
+        if world > 1:
+            t = torch.tensor([sec5], device="cuda", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            sec5 = float(t.item())
+        sync()
+        ke1, pe1, p1 = e5.energy()
+        extra["galaxy_pair_2x8M_bh_mixed_eps1_sharded"] = {
+            "bodies": 1 << 24, "ms_per_step": 1e3 * sec5 / 98, "steps_per_s": 98 / sec5, "steps": 100,
+            "bodies_left": int(e5.stats().n_alive),
+            "drift": {"after_100_steps": {"energy_drift_rel": abs((ke1 + pe1) - (ke0 + pe0)) / abs(ke0 + pe0),
+                                          "momentum_drift_rel": float(np.linalg.norm(p1 - p0)) / pscale}},
+            "stated_bound": "|dE/E0| <= 2e-3 and |dP|/sum m|v| <= 1e-5 after 100 steps (the bounds tests/test_gpu_config5.py asserts on one GPU)",
+            "parallelism": f"targets sharded over {world} GPU(s), replicated build, all-gather of pos+vel per step"}
+        e5.close()
+
     if not args.no_extra and world == 1:
         # benchmark configuration 2: 65,536-body uniform cloud, fp32 direct sum
         u = physics.uniform_cube(65536, seed=1)
@@ -463,42 +490,41 @@ def main():
 
 
     def distributed_tree_extra():
-        """The 16M-body cloud on the key-range-distributed tree, one rank per GPU.  It is the newest multi-process path and
-        runs last: a watchdog prints the line without it should its collectives not come back."""
+        """The two 16M-body scenes on the key-range-distributed tree, one rank per GPU: the fp32 Plummer sphere
+        (configuration 4) and the two galaxies in mixed precision (configuration 5).  It is the newest multi-process path
+        and runs last: a watchdog prints the line without it should its collectives not come back."""
         from nbody_amd.disttree import DistRank, DistributedTree, TorchComm
         m = 1 << 24
-        b = physics.plummer(m, seed=1)
-
-        def dist_ranks(nranks, mine):
-            per = (m + nranks - 1) // nranks
-            out = []
-            for r in mine:
-                dr = DistRank(r, nranks, device=local, precision="f32", theta=0.5)
-                dr.upload(int(per * 1.25) + 4096, b.pos[r * per:(r + 1) * per], b.vel[r * per:(r + 1) * per], b.mass[r * per:(r + 1) * per], r * per)
-                dr.use_torch_stream()
-                out.append(dr)
-            return out
-        ranks = dist_ranks(world, [rank])
-        tree = DistributedTree(ranks, TorchComm())
-        tree.distribute()
-        sec = timed_steps(lambda: tree.step(1), sync, barrier, 2, 5)      # (the first step moves every body to its owner)
-        runs = [tree.step_profiled() for _ in range(5)]
-        acc = {k: float(np.median([t[k] for t in runs])) for k in runs[0]}
-        live = float(ranks[0].engine.stats().n_alive)
-        if world > 1:
-            t = torch.tensor([sec] + [acc[k] for k in sorted(acc)], device="cuda", dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            sec = float(t[0].item())
-            acc = {k: float(v) for k, v in zip(sorted(acc), t[1:].tolist())}
-            t = torch.tensor([live, -live], device="cuda", dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            live = [float(t[0].item()), -float(t[1].item())]
-        extra["bh_theta0.5_fp32_plummer_16M_distributed_tree"] = {
-            "steps_per_s": 5 / sec, "ms_per_step": 1e3 * sec / 5, "phase_ms_max_over_ranks": acc,
-            "bodies_per_rank_max_min": live, "imported_nodes_this_rank": tree.last_import_nodes[0],
-            "migrated_bodies_this_rank": tree.last_migrated[0]}
-        for r in ranks:
-            r.close()
+        per = (m + world - 1) // world
+        for key, b, kw in (("bh_theta0.5_fp32_plummer_16M_distributed_tree", physics.plummer(m, seed=1), dict(precision="f32", theta=0.5)),
+                           ("galaxy_pair_2x8M_bh_mixed_eps1_distributed_tree", physics.galaxy_pair(1 << 23, seed=1),
+                            dict(precision="mixed", theta=0.5, eps=1.0))):
+            r = rank
+            dr = DistRank(r, world, device=local, **kw)
+            dr.upload(int(per * 1.25) + 4096, b.pos[r * per:(r + 1) * per], b.vel[r * per:(r + 1) * per], b.mass[r * per:(r + 1) * per], r * per)
+            dr.use_torch_stream()
+            del b
+            ranks = [dr]
+            tree = DistributedTree(ranks, TorchComm())
+            tree.distribute()
+            sec = timed_steps(lambda: tree.step(1), sync, barrier, 2, 5)      # (the first step moves every body to its owner)
+            runs = [tree.step_profiled() for _ in range(5)]
+            acc = {k: float(np.median([t[k] for t in runs])) for k in runs[0]}
+            live = float(ranks[0].engine.stats().n_alive)
+            if world > 1:
+                t = torch.tensor([sec] + [acc[k] for k in sorted(acc)], device="cuda", dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                sec = float(t[0].item())
+                acc = {k: float(v) for k, v in zip(sorted(acc), t[1:].tolist())}
+                t = torch.tensor([live, -live], device="cuda", dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                live = [float(t[0].item()), -float(t[1].item())]
+            extra[key] = {
+                "steps_per_s": 5 / sec, "ms_per_step": 1e3 * sec / 5, "phase_ms_max_over_ranks": acc,
+                "bodies_per_rank_max_min": live, "imported_nodes_this_rank": tree.last_import_nodes[0],
+                "migrated_bodies_this_rank": tree.last_migrated[0]}
+            for rr in ranks:
+                rr.close()
 
     def emit():
         if rank == 0:
@@ -510,14 +536,16 @@ def main():
 
         def watchdog():
             if not finished.wait(float(os.environ.get("NBODY_BENCH_DIST_TIMEOUT", "300"))):
-                extra["bh_theta0.5_fp32_plummer_16M_distributed_tree"] = {"error": "did not finish in time; the rest of the line is complete"}
+                extra.setdefault("bh_theta0.5_fp32_plummer_16M_distributed_tree", {"error": "did not finish in time; the rest of the line is complete"})
+                extra.setdefault("galaxy_pair_2x8M_bh_mixed_eps1_distributed_tree", {"error": "did not finish in time; the rest of the line is complete"})
                 emit()
                 os._exit(0)
         threading.Thread(target=watchdog, daemon=True).start()
         try:
             distributed_tree_extra()
         except Exception as ex:
-            extra["bh_theta0.5_fp32_plummer_16M_distributed_tree"] = {"error": repr(ex)}
+            extra.setdefault("bh_theta0.5_fp32_plummer_16M_distributed_tree", {"error": repr(ex)})
+            extra.setdefault("galaxy_pair_2x8M_bh_mixed_eps1_distributed_tree", {"error": repr(ex)})
             log("distributed tree extra failed:", ex)
         finished.set()
 
