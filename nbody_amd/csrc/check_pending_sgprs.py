@@ -5,7 +5,8 @@ The walk issues its node loads through inline assembly so that a load and the wa
 apart.  The compiler does not know that the destination registers of such a load are in flight in between: a
 register copy or a reuse scheduled into that window would read or clobber them silently.  This script walks the
 control-flow graph of every kernel in the assembly and fails if any instruction between a scalar load and the next
-`s_waitcnt lgkmcnt(0)` on some path touches the load's destination registers.
+`s_waitcnt lgkmcnt(0)` on some path touches the load's destination registers.  It also checks that M0, which the
+walk's inline assembly sets without the compiler's knowledge, is used by nothing else (check_m0).
 
 usage: check_pending_sgprs.py file.s
 """
@@ -108,6 +109,25 @@ def check(name, lines):
     return sorted(problems)
 
 
+def check_m0(lines):
+    """The walk pushes onto its stack of cell ends with `s_mov_b32 m0, <lane>; s_nop 0; v_writelane_b32 v, s, m0` from
+    inline assembly and does not tell the compiler (M0 is reserved: it cannot be named as clobbered).  That is sound only
+    while nothing else in the kernel uses M0: every other mention of it is reported."""
+    bad = []
+    insts = [l for l in lines if not l.endswith(":")]
+    for k, line in enumerate(insts):
+        if not re.search(r"\bm0\b", line):
+            continue
+        if line.startswith("s_mov_b32 m0,"):
+            follow = insts[k + 1:k + 3]
+            if len(follow) == 2 and follow[0].startswith("s_nop") and follow[1].startswith("v_writelane_b32") and follow[1].endswith(", m0"):
+                continue
+        elif line.startswith("v_writelane_b32") and line.endswith(", m0") and k >= 2 and insts[k - 2].startswith("s_mov_b32 m0,"):
+            continue
+        bad.append(line)
+    return bad
+
+
 def main():
     asm = open(sys.argv[1]).read()
     bad = 0
@@ -116,6 +136,9 @@ def main():
         n += 1
         for line in check(name, lines):
             print(f"{name}: touches scalar registers of a load in flight: {line}", file=sys.stderr)
+            bad += 1
+        for line in check_m0(lines):
+            print(f"{name}: uses M0 outside the walk's lane write: {line}", file=sys.stderr)
             bad += 1
     if n == 0:
         print("no kernels found in", sys.argv[1], file=sys.stderr)

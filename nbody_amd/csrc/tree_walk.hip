@@ -94,7 +94,8 @@ __device__ __forceinline__ float capped(float x) { return x; }
 __device__ __forceinline__ void write_lane(int& v, int value, int lane)
 {
     // (one scalar register per vector instruction on this chip: the lane number goes through M0, which the compiler
-    // reserves and sets itself in front of any instruction of its own that reads it; none in this file does)
+    // reserves and sets itself in front of any instruction of its own that reads it; none in this file does, and the
+    // build's check of the device assembly fails if that changes)
     asm("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(v) : "s"(value), "s"(lane));
 }
 

@@ -57,3 +57,12 @@ def test_read_on_the_branch_path_is_flagged():
 def test_overwrite_of_pending_registers_is_flagged():
     bad = GOOD.replace("\tv_mov_b32_e32 v4, s15\n", "\ts_mov_b32 s23, 0\n")
     assert problems(bad) == ["s_mov_b32 s23, 0"]
+
+
+def test_m0_may_only_serve_the_lane_write():
+    ok = ["s_mov_b32 m0, s33", "s_nop 0", "v_writelane_b32 v3, s36, m0", "s_endpgm"]
+    assert chk.check_m0(ok) == []
+    assert chk.check_m0(ok[:1] + ["v_add_f32_e32 v0, v1, v2"] + ok[1:]) != []        # the sequence was split up
+    assert chk.check_m0(ok + ["s_movrels_b32 s4, s8"]) == []                          # (no mention of m0: not this check's business)
+    assert chk.check_m0(["s_mov_b32 m0, -1", "ds_read_b32 v1, v2", "s_endpgm"]) == ["s_mov_b32 m0, -1"]
+    assert chk.check_m0(["v_readlane_b32 s4, v3, m0"]) == ["v_readlane_b32 s4, v3, m0"]
