@@ -47,7 +47,8 @@ struct NodeD {
     double w;           // cell edge
     int skip;
     int pad0;
-    double pad1[2];
+    double w2;          // edge * edge, the left side of the walk's opening test (one product less per visit and lane)
+    double pad1;
 };
 static_assert(sizeof(NodeD) == 64, "NodeD must be 64 bytes");
 

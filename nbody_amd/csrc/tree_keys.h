@@ -75,5 +75,5 @@ template <> __device__ __forceinline__ void set_edge<NodeF>(NodeF& nd, double w,
     const double q = theta > 0.0 ? (w / theta) * (w / theta) : (w > 0.0 ? 3.0e38 : 0.0);
     nd.w2 = (float)fmin(w > 0.0 ? q + eps2 : q, 3.0e38);
 }
-template <> __device__ __forceinline__ void set_edge<NodeD>(NodeD& nd, double w, double, double) { nd.w = w; }
+template <> __device__ __forceinline__ void set_edge<NodeD>(NodeD& nd, double w, double, double) { nd.w = w; nd.w2 = w * w; }
 

@@ -21,7 +21,7 @@
 // uniform *float* values with vector instructions (v_mov + v_cndmask per field), so the records are handled as
 // integer bit patterns (scalar s_cselect) and turned into floats only where a lane consumes them.
 struct RawF { unsigned x, y, z, m, w2; int skip; };
-struct RawD { unsigned long long x, y, z, m, w; int skip; };
+struct RawD { unsigned long long x, y, z, m, w, w2; int skip; };
 
 __device__ __forceinline__ RawF load_raw(const NodeF* __restrict__ nodes, int i)
 {
@@ -35,10 +35,10 @@ __device__ __forceinline__ RawF load_raw(const NodeF* __restrict__ nodes, int i)
 }
 __device__ __forceinline__ RawD load_raw(const NodeD* __restrict__ nodes, int i)
 {
-    const ulonglong4 a = *reinterpret_cast<const ulonglong4*>(nodes + i);
-    const ulonglong1 w = *reinterpret_cast<const ulonglong1*>(reinterpret_cast<const char*>(nodes + i) + 32);
-    const int sk = *reinterpret_cast<const int*>(reinterpret_cast<const char*>(nodes + i) + 40);
-    return RawD{a.x, a.y, a.z, a.w, w.x, sk};
+    // the whole 64-byte record, one cache line, in one request (s_load_dwordx16): requests per visit matter more than bytes
+    typedef unsigned long long u8l __attribute__((ext_vector_type(8)));
+    const u8l a = *reinterpret_cast<const u8l*>(__builtin_assume_aligned(nodes + i, 64));
+    return RawD{a[0], a[1], a[2], a[3], a[4], a[6], (int)(unsigned)a[5]};
 }
 // The same request split in two: `request_raw` issues the load and returns at once, `arrived` waits for it.  The
 // compiler schedules a plain load next to its first use, which in the walk is one whole visit too late (a plain
@@ -105,7 +105,7 @@ __device__ __forceinline__ RawF pick(bool c, const RawF& a, const RawF& b)
 }
 __device__ __forceinline__ RawD pick(bool c, const RawD& a, const RawD& b)
 {
-    return RawD{c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z, c ? a.m : b.m, c ? a.w : b.w, c ? a.skip : b.skip};
+    return RawD{c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z, c ? a.m : b.m, c ? a.w : b.w, c ? a.w2 : b.w2, c ? a.skip : b.skip};
 }
 __device__ __forceinline__ float as_real(unsigned v) { return __uint_as_float(v); }
 __device__ __forceinline__ double as_real(unsigned long long v) { return __longlong_as_double((long long)v); }
@@ -133,7 +133,7 @@ __device__ __forceinline__ bool node_opens(const RawF& nd, float r2, float, unsi
 __device__ __forceinline__ bool node_opens(const RawD& nd, double r2, double theta)
 {
     const double w = as_real(nd.w);
-    const double a = w * w, b = (theta * theta) * r2;
+    const double a = as_real(nd.w2), b = (theta * theta) * r2;
     bool open = a > b;
     const unsigned long long ia = (unsigned long long)__double_as_longlong(a), ib = (unsigned long long)__double_as_longlong(b);
     const bool unsure = ia - ib + 1024ull <= 2048ull;
@@ -145,7 +145,7 @@ __device__ __forceinline__ bool node_opens(const RawD& nd, double r2, double the
 __device__ __forceinline__ bool node_opens(const RawD& nd, double r2, double theta, unsigned long long& opening)
 {
     const double w = as_real(nd.w);
-    const double a = w * w, b = (theta * theta) * r2;
+    const double a = as_real(nd.w2), b = (theta * theta) * r2;
     bool open = a > b;
     opening = __builtin_amdgcn_ballot_w64(a > b);
     const unsigned long long ia = (unsigned long long)__double_as_longlong(a), ib = (unsigned long long)__double_as_longlong(b);
