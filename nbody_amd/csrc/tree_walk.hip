@@ -46,7 +46,7 @@ __device__ __forceinline__ RawD load_raw(const NodeD* __restrict__ nodes, int i)
 // Between the two calls the destination registers are in flight and the compiler does not know it: the build
 // checks the device assembly for any instruction that touches them in that window (check_pending_sgprs.py).
 struct PendingF { unsigned v __attribute__((ext_vector_type(8))); };
-struct PendingD { RawD r; };
+struct PendingD { unsigned long long v __attribute__((ext_vector_type(8))); };     // the 64-byte fp64 record in flight
 // `after` is passed through a second statement that the compiler may not move ahead of the request: whatever is
 // computed from it stays behind the request in program order.
 __device__ __forceinline__ PendingF request_raw(const NodeF* __restrict__ nodes, int i, float& after)
@@ -62,9 +62,9 @@ __device__ __forceinline__ RawF arrived(PendingF& p)
     return RawF{p.v[0], p.v[1], p.v[2], p.v[3], p.v[4], (int)p.v[5]};
 }
 __device__ __forceinline__ void settle(PendingF& p, PendingF& q) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(p.v), "+s"(q.v)); }
-__device__ __forceinline__ void settle(PendingD&, PendingD&) {}
+__device__ __forceinline__ void settle(PendingD& p, PendingD& q) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(p.v), "+s"(q.v)); }
 __device__ __forceinline__ void settle(PendingF& p) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(p.v)); }
-__device__ __forceinline__ void settle(PendingD&) {}
+__device__ __forceinline__ void settle(PendingD& p) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(p.v)); }
 // A second form of the wait, for the kernel in which the register allocator answered the first with copies ahead of the
 // wait (two bodies per lane in mixed precision: it gave the value in flight and the value arrived different registers,
 // and a tied operand is satisfied by a copy).  Here the record is a plain input that is never redefined, and the wait is
@@ -77,8 +77,21 @@ __device__ __forceinline__ RawF arrived_behind(PendingF& p, P& x, P& y, P& z)
     return RawF{p.v[0], p.v[1], p.v[2], p.v[3], p.v[4], (int)p.v[5]};
 }
 __device__ __forceinline__ void settle_plain(PendingF& p) { asm volatile("s_waitcnt lgkmcnt(0)" :: "s"(p.v)); }
-__device__ __forceinline__ PendingD request_raw(const NodeD* __restrict__ nodes, int i, double&) { return PendingD{load_raw(nodes, i)}; }
-__device__ __forceinline__ RawD arrived(PendingD& p) { return p.r; }
+// (fp64 records: a plain load was waited for at the end of every second visit, where the compiler copied the next
+// record's centre to vector registers for the first of its two unrolled visits; 64-bit address, because 2^27 records of
+// 64 bytes do not fit a 32-bit byte offset)
+__device__ __forceinline__ PendingD request_raw(const NodeD* __restrict__ nodes, int i, double& after)
+{
+    PendingD p;
+    asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=s"(p.v) : "s"(nodes + i));
+    asm volatile("" : "+v"(after));
+    return p;
+}
+__device__ __forceinline__ RawD arrived(PendingD& p)
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(p.v));
+    return RawD{p.v[0], p.v[1], p.v[2], p.v[3], p.v[4], p.v[6], (int)(unsigned)p.v[5]};
+}
 
 // min(x, 1e300) for an x that is never NaN (fmin would first quieten x with an instruction of its own)
 __device__ __forceinline__ double capped(double x)
