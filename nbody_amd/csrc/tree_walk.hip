@@ -134,22 +134,29 @@ __device__ __forceinline__ bool node_opens(const RawF& nd, float r2, float, unsi
     opening = __builtin_amdgcn_ballot_w64(open);
     return open;
 }
+// Whether two non-negative doubles may be within rounding of each other, erring on the side of yes: their upper words
+// (sign, exponent, top 20 mantissa bits) differ by at most one, i.e. they agree to about 1e-6 or better.  Three 32-bit
+// instructions; the exact distance of the bit patterns would take five, and the wider net costs nothing: about one
+// wave-visit in ten thousand has a lane in it.
+__device__ __forceinline__ bool close_products(double a, double b)
+{
+    const unsigned ha = (unsigned)((unsigned long long)__double_as_longlong(a) >> 32);
+    const unsigned hb = (unsigned)((unsigned long long)__double_as_longlong(b) >> 32);
+    return ha - hb + 1u <= 2u;
+}
+
 // The fp64 expression costs a square root and a division (about half of the visit's instructions), and its verdict
 // is that of  edge^2 > theta^2 * r^2  unless the two sides agree to within the rounding of either form.  So the
-// products decide, and only when some lane of the wave finds them within 1024 units in the last place of each other
-// (2.3e-13 relative, a few hundred times the combined rounding error of both forms) does the wave evaluate the
-// reference's expression.  Both sides are non-negative, so their distance in units in the last place is the distance of
-// their bit patterns, taken with integer instructions at twice the rate of the fp64 ones (a relative test in floating
-// point took six fp64 instructions here).  A lane that sits out carries r^2 = infinity: its pattern is far from any
-// finite edge^2 and the verdict "closed" is certain; r^2 = 0 against a leaf's edge 0 is within the window and goes the
-// reference's way (0 / 0 > theta is false).
+// products decide, and only when some lane of the wave finds them close (close_products: a net thousands of times wider
+// than the combined rounding error of both forms, and still rarely hit) does the wave evaluate the reference's
+// expression.  A lane that sits out carries r^2 = infinity: its pattern is far from any finite edge^2 and the verdict
+// "closed" is certain; r^2 = 0 against a leaf's edge 0 is close and goes the reference's way (0 / 0 > theta is false).
 __device__ __forceinline__ bool node_opens(const RawD& nd, double r2, double theta)
 {
     const double w = as_real(nd.w);
     const double a = as_real(nd.w2), b = (theta * theta) * r2;
     bool open = a > b;
-    const unsigned long long ia = (unsigned long long)__double_as_longlong(a), ib = (unsigned long long)__double_as_longlong(b);
-    const bool unsure = ia - ib + 1024ull <= 2048ull;
+    const bool unsure = close_products(a, b);
     if (__builtin_amdgcn_ballot_w64(unsure) != 0) open = w / sqrt(r2) > theta;
     return open;
 }
@@ -161,8 +168,7 @@ __device__ __forceinline__ bool node_opens(const RawD& nd, double r2, double the
     const double a = as_real(nd.w2), b = (theta * theta) * r2;
     bool open = a > b;
     opening = __builtin_amdgcn_ballot_w64(a > b);
-    const unsigned long long ia = (unsigned long long)__double_as_longlong(a), ib = (unsigned long long)__double_as_longlong(b);
-    const bool unsure = ia - ib + 1024ull <= 2048ull;
+    const bool unsure = close_products(a, b);
     if (__builtin_amdgcn_ballot_w64(unsure) != 0) {
         const double q = w / sqrt(r2);
         open = q > theta;
