@@ -47,7 +47,7 @@ struct NodeD {
     double w;           // cell edge
     int skip;
     int pad0;
-    double w2;          // edge * edge, the left side of the walk's opening test (one product less per visit and lane)
+    double w2;          // (edge / theta)^2: the walk's first look at the opening test is r^2 < w2, without a product
     double pad1;
 };
 static_assert(sizeof(NodeD) == 64, "NodeD must be 64 bytes");

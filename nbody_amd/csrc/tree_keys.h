@@ -75,5 +75,11 @@ template <> __device__ __forceinline__ void set_edge<NodeF>(NodeF& nd, double w,
     const double q = theta > 0.0 ? (w / theta) * (w / theta) : (w > 0.0 ? 3.0e38 : 0.0);
     nd.w2 = (float)fmin(w > 0.0 ? q + eps2 : q, 3.0e38);
 }
-template <> __device__ __forceinline__ void set_edge<NodeD>(NodeD& nd, double w, double, double) { nd.w = w; nd.w2 = w * w; }
+template <> __device__ __forceinline__ void set_edge<NodeD>(NodeD& nd, double w, double theta, double)
+{
+    nd.w = w;
+    // (edge / theta)^2, what the walk compares r^2 with before it consults the reference's own expression; theta = 0
+    // ("always open") maps to infinity for a cell and to 0 for a leaf, which never opens
+    nd.w2 = theta > 0.0 ? (w / theta) * (w / theta) : (w > 0.0 ? (double)INFINITY : 0.0);
+}
 

@@ -146,15 +146,16 @@ __device__ __forceinline__ bool close_products(double a, double b)
 }
 
 // The fp64 expression costs a square root and a division (about half of the visit's instructions), and its verdict
-// is that of  edge^2 > theta^2 * r^2  unless the two sides agree to within the rounding of either form.  So the
-// products decide, and only when some lane of the wave finds them close (close_products: a net thousands of times wider
-// than the combined rounding error of both forms, and still rarely hit) does the wave evaluate the reference's
-// expression.  A lane that sits out carries r^2 = infinity: its pattern is far from any finite edge^2 and the verdict
-// "closed" is certain; r^2 = 0 against a leaf's edge 0 is close and goes the reference's way (0 / 0 > theta is false).
+// is that of  (edge / theta)^2 > r^2  unless the two sides agree to within the rounding of either form.  So the
+// squares decide (the left one is stored in the record), and only when some lane of the wave finds them close
+// (close_products: a net thousands of times wider than the combined rounding error of both forms, and still rarely
+// hit) does the wave evaluate the reference's expression.  A lane that sits out carries r^2 = infinity: its pattern is
+// far from any finite (edge / theta)^2 and the verdict "closed" is certain; r^2 = 0 against a leaf's edge 0 is close
+// and goes the reference's way (0 / 0 > theta is false).
 __device__ __forceinline__ bool node_opens(const RawD& nd, double r2, double theta)
 {
     const double w = as_real(nd.w);
-    const double a = as_real(nd.w2), b = (theta * theta) * r2;
+    const double a = as_real(nd.w2), b = r2;
     bool open = a > b;
     const bool unsure = close_products(a, b);
     if (__builtin_amdgcn_ballot_w64(unsure) != 0) open = w / sqrt(r2) > theta;
@@ -165,7 +166,7 @@ __device__ __forceinline__ bool node_opens(const RawD& nd, double r2, double the
 __device__ __forceinline__ bool node_opens(const RawD& nd, double r2, double theta, unsigned long long& opening)
 {
     const double w = as_real(nd.w);
-    const double a = as_real(nd.w2), b = (theta * theta) * r2;
+    const double a = as_real(nd.w2), b = r2;
     bool open = a > b;
     opening = __builtin_amdgcn_ballot_w64(a > b);
     const bool unsure = close_products(a, b);
