@@ -639,8 +639,14 @@ __global__ __launch_bounds__(WALK_BLOCK) void walk_pair_kernel(
         const float w2 = as_real(nd.w2);
         const bool open0 = r2.x < w2, open1 = r2.y < w2;
         // (two ballots joined by a scalar OR: the ballot of "open0 || open1" goes through a vector register)
-        const unsigned long long opening = __builtin_amdgcn_ballot_w64(open0) | __builtin_amdgcn_ballot_w64(open1);
-        const int next = opening != 0 ? cur + 1 : skip;
+        // (the OR of the two votes sets the scalar condition code that picks the next node: written out, because the
+        // compiler compares the mask with zero again and turns the verdict into a mask and back on the way to the request)
+        unsigned long long opening;
+        int next;
+        asm("s_or_b64 %0, %2, %3\n\ts_cselect_b32 %1, %4, %5"
+            : "=&s"(opening), "=s"(next)
+            : "s"(__builtin_amdgcn_ballot_w64(open0)), "s"(__builtin_amdgcn_ballot_w64(open1)), "s"(cur + 1), "s"(skip)
+            : "scc");
         float keep = r2.x;
         there = request_raw(nodes, next, keep);    // the force arithmetic below runs while this is in flight
         r2.x = keep;
