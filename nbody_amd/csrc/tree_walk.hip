@@ -329,7 +329,13 @@ __global__ __launch_bounds__(WALK_BLOCK) void walk_kernel(
         const R rtest = active ? (SOFT ? r2 - floor2v : r2) : (R)INFINITY;
         unsigned long long opening;
         const bool open = node_opens(nd, rtest, theta, opening);
-        const int next = opening != 0 ? cur + 1 : skip;
+        int next;
+        if constexpr (__is_same(NodeT, NodeD)) {
+            // (written out: on the way from the fp64 vote to the request the compiler turns the verdict into a mask and back)
+            asm("s_cmp_lg_u64 %1, 0\n\ts_cselect_b32 %0, %2, %3" : "=s"(next) : "s"(opening), "s"(cur + 1), "s"(skip) : "scc");
+        } else {
+            next = opening != 0 ? cur + 1 : skip;
+        }
         there = request_raw(nodes, next, r2);      // the force arithmetic below runs while this is in flight
         const R mass = as_real(nd.m);
         bool counted = false;
