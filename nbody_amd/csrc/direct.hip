@@ -39,7 +39,7 @@ template <int ITILE> struct Targets<double, ITILE> {
             for (int k = 0; k < ITILE; k++) {
                 const double dx = s.x - px[k], dy = s.y - py[k], dz = s.z - pz[k];
                 const double r2 = fma(dx, dx, fma(dy, dy, fma(dz, dz, floor2)));
-                const double rinv = rsq_dev(r2);
+                const double rinv = rsq2_dev(r2);             // twice 1/r: the sums carry a factor 8, see direct_kernel's G
                 const double w = (rinv * rinv) * (rinv * s.w);
                 gx[k] = fma(dx, w, gx[k]); gy[k] = fma(dy, w, gy[k]); gz[k] = fma(dz, w, gz[k]);
             }
@@ -81,6 +81,9 @@ __global__ __launch_bounds__(BLOCK) void direct_kernel(
         ax[k] = 0; ay[k] = 0; az[k] = 0;
     }
 
+    // (fp64 pair arithmetic works with 2/r, rsq2_dev: its sums are exactly 8 times the plain ones.  G takes the factor
+    // back here; partial sums are stored as they are and the caller hands the finishing kernel G / 8)
+    if (__is_same(R, double)) G = G * (A)0.125;
     const int jb = blockIdx.y * jchunk;
     const int je = (jb + jchunk < n_src) ? jb + jchunk : n_src;
     for (int jt = jb; jt < je; jt += DIRECT_TILE) {
@@ -322,12 +325,13 @@ static int launch_direct(nbe_engine* e, const void* src, uint64_t t0, uint64_t t
                        mirror_out);
     NBE_HIP(hipGetLastError());
     dim3 fgrid(cdiv(nt, 256));
+    const A Gfin = __is_same(R, double) ? G * (A)0.125 : G;      // (the fp64 kernel's partial sums carry a factor 8)
     if (fused)
         hipLaunchKernelGGL((direct_finish_kernel<A, true>), fgrid, dim3(256), 0, e->stream, (const A4*)e->partial,
-                           (int)jsplit, (int)t0, (int)t1, G, dt, acc, pos_in, vel_in, pos_out, vel_out, mirror_out);
+                           (int)jsplit, (int)t0, (int)t1, Gfin, dt, acc, pos_in, vel_in, pos_out, vel_out, mirror_out);
     else
         hipLaunchKernelGGL((direct_finish_kernel<A, false>), fgrid, dim3(256), 0, e->stream, (const A4*)e->partial,
-                           (int)jsplit, (int)t0, (int)t1, G, dt, acc, pos_in, vel_in, pos_out, vel_out, mirror_out);
+                           (int)jsplit, (int)t0, (int)t1, Gfin, dt, acc, pos_in, vel_in, pos_out, vel_out, mirror_out);
     NBE_HIP(hipGetLastError());
     return NBE_OK;
 }

@@ -16,6 +16,17 @@ __device__ __forceinline__ double rsq_dev(double x)
     return y;
 }
 
+// 2 / sqrt(x): the same Newton step written as y (3 - x y^2), which leaves out the halvings of y (1.5 - 0.5 x y^2):
+// three fp64 instructions behind v_rsq_f64 instead of four.  Scaling by two is exact at every step, so the result is
+// exactly twice rsq_dev's; a kernel that sums dx * m * rinv^3 with it carries a factor of exactly 8 and multiplies
+// its sum by G / 8 at the end: the same bits as with rsq_dev, one instruction less per interaction.
+__device__ __forceinline__ double rsq2_dev(double x)
+{
+    const double y = __builtin_amdgcn_rsq(x);
+    const double t = x * y;
+    return y * fma(-t, y, 3.0);
+}
+
 // What a force kernel does with a target's acceleration sum.
 enum { OUT_ACC = 0,       // store G*sum to the acceleration buffer
        OUT_FUSED = 1,     // integrate the body (kick_drift) into the next-state buffers

@@ -361,7 +361,9 @@ __global__ __launch_bounds__(WALK_BLOCK) void walk_kernel(
         }
         // (fp64: the Newton step behind v_rsq_f64 turns rsq(inf) = 0 into NaN.  With events, infinity is capped at 1e300,
         // whose weight 1e-450 * mass underflows to exactly 0: one instruction instead of a compare and two selects.)
-        const R rinv = rsq_dev(EVENTS && !__is_same(R, float) ? capped(r2) : r2);
+        // (fp64 works with 2/r, rsq2_dev: one instruction less, the sums carry a factor of exactly 8 that G takes back)
+        R rinv;
+        if constexpr (__is_same(R, double)) rinv = rsq2_dev(capped(r2)); else rinv = rsq_dev(r2);
         R rinv2 = rinv * rinv;
         // (keeps the compiler from pairing the two products in one packed multiply, for which it copies the mass
         // to a vector register: one more instruction that reads a scalar register)
@@ -416,11 +418,12 @@ __global__ __launch_bounds__(WALK_BLOCK) void walk_kernel(
     if (!valid) return;
     if constexpr (BLOCKED) { ax = tot[0][threadIdx.x]; ay = tot[1][threadIdx.x]; az = tot[2][threadIdx.x]; }
     const A sx = ax + (A)fx, sy = ay + (A)fy, sz = az + (A)fz;
+    const A Gs = __is_same(R, double) ? G * (A)0.125 : G;         // (fp64 sums: 8 times the plain ones, see the visit)
     if (OUT == OUT_ACC) {
-        A4 o; o.x = G * sx; o.y = G * sy; o.z = G * sz; o.w = phi;
+        A4 o; o.x = Gs * sx; o.y = Gs * sy; o.z = Gs * sz; o.w = __is_same(R, double) ? phi * (A)0.5 : phi;
         acc_out[i] = o;
     } else {
-        kick_drift<A>(i, G * sx, G * sy, G * sz, dt, pos_in, vel_in, pos_out, vel_out, mirror_out);
+        kick_drift<A>(i, Gs * sx, Gs * sy, Gs * sz, dt, pos_in, vel_in, pos_out, vel_out, mirror_out);
     }
 }
 
