@@ -633,7 +633,8 @@ __global__ __launch_bounds__(WALK_BLOCK) void walk_pair_kernel(
     unsigned count = 0;
     int cur = 0;
     auto visit = [&](auto& here, auto& there) -> bool {
-        const auto nd = BLOCKED ? arrived_behind(here, px, py, pz) : arrived(here);
+        RawF nd;
+        if constexpr (BLOCKED) nd = arrived_behind(here, px, py, pz); else nd = arrived(here);
         const int skip = nd.skip;
         asm volatile("" : "+s"(cur));             // (keeps the compare behind the wait, as in walk_kernel)
         if (cur == next_wake) {                   // the cursor leaves the innermost cell in which bodies sleep
