@@ -266,7 +266,9 @@ def main():
             dist.all_reduce(t)
             i3 = float(t.item())
         extra["bh_theta0.5_fp32_plummer_16M"] = {"steps_per_s": 5 / s3, "ms_per_step": 1e3 * s3 / 5,
-                                                 "interactions_per_s": i3 * 5 / s3, "force_kernel_ms": kms3}
+                                                 "interactions_per_step": i3, "interactions_per_s": i3 * 5 / s3, "force_kernel_ms": kms3,
+                                                 "force_kernel": "walk_pair_kernel<float> (two bodies per lane)" if world == 1 else "by the shard's size",
+                                                 "force_kernel_frac_of_fp32_valu_peak": (i3 / world) * FLOP_PER_INTERACTION / (kms3 * 1e-3) / 1e12 / FP32_VALU_PEAK_TFLOPS}
         if st3 is not None:
             extra["bh_theta0.5_fp32_plummer_16M"].update({
                 "ms_sort": st3.ms_sort, "ms_build": st3.ms_build, "ms_force": st3.ms_force,
