@@ -93,15 +93,6 @@ __device__ __forceinline__ RawD arrived(PendingD& p)
     return RawD{p.v[0], p.v[1], p.v[2], p.v[3], p.v[4], p.v[6], (int)(unsigned)p.v[5]};
 }
 
-// min(x, 1e300) for an x that is never NaN (fmin would first quieten x with an instruction of its own)
-__device__ __forceinline__ double capped(double x)
-{
-    double c;
-    asm("v_min_f64 %0, %1, %2" : "=v"(c) : "v"(x), "v"(1e300));
-    return c;
-}
-__device__ __forceinline__ float capped(float x) { return x; }
-
 // v[lane] = value for a wave-uniform value and lane number, both in scalar registers produced by scalar instructions (a
 // lane number written by a vector instruction would need four wait states in front of this one).
 __device__ __forceinline__ void write_lane(int& v, int value, int lane)
@@ -149,8 +140,8 @@ __device__ __forceinline__ bool close_products(double a, double b)
 // is that of  (edge / theta)^2 > r^2  unless the two sides agree to within the rounding of either form.  So the
 // squares decide (the left one is stored in the record), and only when some lane of the wave finds them close
 // (close_products: a net thousands of times wider than the combined rounding error of both forms, and still rarely
-// hit) does the wave evaluate the reference's expression.  A lane that sits out carries r^2 = infinity: its pattern is
-// far from any finite (edge / theta)^2 and the verdict "closed" is certain; r^2 = 0 against a leaf's edge 0 is close
+// hit) does the wave evaluate the reference's expression.  A lane that sits out carries r^2 = 1e300: far from any finite
+// (edge / theta)^2, so the verdict "closed" is certain; r^2 = 0 against a leaf's edge 0 is close
 // and goes the reference's way (0 / 0 > theta is false).
 __device__ __forceinline__ bool node_opens(const RawD& nd, double r2, double theta)
 {
@@ -284,9 +275,9 @@ __global__ __launch_bounds__(WALK_BLOCK) void walk_kernel(
     // a vector instruction that reads a scalar register issues at half rate: keep the loop's constant in a vector one
     R floor2v = floor2;
     asm volatile("" : "+v"(floor2v));
-    // Sleeping lanes.  A lane that sits out carries +infinity where the others carry the floor under r^2: its distance
-    // to every node is infinite, so it opens nothing and receives nothing (rsq(inf) = 0), without a test of its own in
-    // the visit.  Lanes fall asleep only where the cursor descends into a cell that they accept, and wake where the
+    // Sleeping lanes.  A lane that sits out carries +infinity (fp64: 1e300, see FAR) where the others carry the floor under
+    // r^2: its distance to every node is infinite, so it opens nothing and receives nothing (rsq(inf) = 0), without a
+    // test of its own in the visit.  Lanes fall asleep only where the cursor descends into a cell that they accept, and wake where the
     // cursor leaves that cell; both are events of the whole wave, decided on scalar values, and rare (about a sixth of
     // the visits each).  The ends of the cells in which lanes sleep are nested: the innermost in next_wake, the ones
     // around it on a stack kept in the lanes of one vector register (at most one entry per depth of the tree).
@@ -294,7 +285,13 @@ __global__ __launch_bounds__(WALK_BLOCK) void walk_kernel(
     // events made the kernel slower at 16M bodies (two galaxies: 37.6 against 36.0 ms), and without the explicit mask on
     // the weight the compiler copies record registers while a request is in flight.
     constexpr bool EVENTS = !BLOCKED;
-    R seed = (walked || !EVENTS) ? floor2v : (R)INFINITY;
+    // "Infinitely far": what a lane that takes nothing carries as r^2.  fp32: +infinity (v_rsq_f32 makes 0 of it).  fp64:
+    // 1e300, because the Newton step behind v_rsq_f64 makes NaN of infinity; the weight of 1e300, 1e-450 times the mass,
+    // underflows to exactly 0, and no threshold (edge / theta)^2 comes near it (theta = 0 stores infinity, but then no lane
+    // ever accepts a cell, so none sleeps).  Anything at or beyond FAR_TEST counts as far.
+    constexpr R FAR = __is_same(R, double) ? (R)1e300 : (R)INFINITY;
+    constexpr R FAR_TEST = __is_same(R, double) ? (R)1e299 : (R)INFINITY;
+    R seed = (walked || !EVENTS) ? floor2v : FAR;
     int next_wake = 0x7fffffff, sp = 0, ends = 0;
     unsigned count = 0;
     int it = 0;
@@ -326,7 +323,7 @@ __global__ __launch_bounds__(WALK_BLOCK) void walk_kernel(
         R r2 = fma(dx, dx, fma(dy, dy, fma(dz, dz, seed)));
         // sleeping lanes have an infinite distance, so one compare is both the opening test and the vote
         const bool active = EVENTS || cur >= my_skip;
-        const R rtest = active ? (SOFT ? r2 - floor2v : r2) : (R)INFINITY;
+        const R rtest = active ? (SOFT ? r2 - floor2v : r2) : FAR;
         unsigned long long opening;
         const bool open = node_opens(nd, rtest, theta, opening);
         int next;
@@ -339,17 +336,17 @@ __global__ __launch_bounds__(WALK_BLOCK) void walk_kernel(
         there = request_raw(nodes, next, r2);      // the force arithmetic below runs while this is in flight
         const R mass = as_real(nd.m);
         bool counted = false;
-        if (COUNT) counted = active && !open && r2 < (R)INFINITY && (dx != (R)0 || dy != (R)0 || dz != (R)0);
+        if (COUNT) counted = active && !open && r2 < FAR_TEST && (dx != (R)0 || dy != (R)0 || dz != (R)0);
         const bool take = active && !open;
         if (!EVENTS && take) my_skip = skip;
         if (EVENTS && opening != 0) {
             // the cursor descends: the lanes that accept the cell sleep until the cursor reaches its end
-            const bool fin = r2 < (R)INFINITY;
+            const bool fin = r2 < FAR_TEST;
             const bool rest = !open && fin;
             // (the vote on "somebody rests" from the masks of the plain compares: the ballot of a combined condition goes
             // through a vector register and back)
             if ((__builtin_amdgcn_ballot_w64(fin) & ~opening) != 0) {
-                if (rest) { my_skip = skip; seed = (R)INFINITY; }
+                if (rest) { my_skip = skip; seed = FAR; }
                 // push the end of the cell around this one (a last child ends where its parent ends: one wake for both,
                 // nothing pushed; the write below is then overwritten by the next push)
                 write_lane(ends, next_wake, sp);
@@ -357,13 +354,11 @@ __global__ __launch_bounds__(WALK_BLOCK) void walk_kernel(
                 next_wake = skip;
             }
             // a lane that opens the cell takes nothing from it: an infinite distance gives it the weight 0
-            if (open) r2 = (R)INFINITY;
+            if (open) r2 = FAR;
         }
-        // (fp64: the Newton step behind v_rsq_f64 turns rsq(inf) = 0 into NaN.  With events, infinity is capped at 1e300,
-        // whose weight 1e-450 * mass underflows to exactly 0: one instruction instead of a compare and two selects.)
         // (fp64 works with 2/r, rsq2_dev: one instruction less, the sums carry a factor of exactly 8 that G takes back)
         R rinv;
-        if constexpr (__is_same(R, double)) rinv = rsq2_dev(capped(r2)); else rinv = rsq_dev(r2);
+        if constexpr (__is_same(R, double)) rinv = rsq2_dev(r2); else rinv = rsq_dev(r2);
         R rinv2 = rinv * rinv;
         // (keeps the compiler from pairing the two products in one packed multiply, for which it copies the mass
         // to a vector register: one more instruction that reads a scalar register)
