@@ -24,5 +24,6 @@ run 300 rocprofv3 --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_
 run 300 rocprofv3 --pmc GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_grbm_direct" -- python3 bench.py --steps 2 --warmup 0 --no-cpu-baseline --no-extra > /dev/null 2> "$OUT/pmc8.err" || exit 1
 run 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_dist" -- python3 profiles/dist_step.py > "$OUT/dist_step.log" 2> "$OUT/dist_step.err" || exit 1
 run 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_walk16" -- python3 profiles/walk_16M.py > "$OUT/walk_16M.log" 2> "$OUT/walk_16M.err" || exit 1
+run 300 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAIT_INST_ANY --output-format csv -d "$OUT/pmc_sq_walk16" -- python3 profiles/walk_16M.py > /dev/null 2> "$OUT/pmc9.err" || exit 1
 find "$OUT" -name "*.csv" | head -40 >&2
 python3 profiles/summarise.py "$TAG"

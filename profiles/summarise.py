@@ -113,17 +113,31 @@ if agg:
 
 # ---- counters ----
 pmc = defaultdict(lambda: defaultdict(lambda: [0, 0.0]))
+def walk_name(full):
+    """walk kernels by precision and instrumentation (the two 16M-body workloads run several of them)"""
+    name = full.replace("void ", "").split("(")[0].split("<")[0]
+    args = [a.strip() for a in full.split("(")[0].split("<", 1)[1].rstrip(">").split(",")]
+    if name == "walk_pair_kernel":
+        prec, counting = ("mixed" if args[0] == "double" else "f32"), args[2] == "true"
+    else:
+        prec = "f64" if args[0] == "double" else "mixed" if args[1] == "double" else "f32"
+        counting = args[4] == "true"
+    return name + f"<{prec}>" + (" instrumented" if counting else "")
+
+
 for sub in ("pmc_fetch_direct", "pmc_write_direct", "pmc_fetch_tree", "pmc_write_tree", "pmc_sq_direct", "pmc_sq_tree",
-            "pmc_lds_tree", "pmc_grbm_direct"):
+            "pmc_lds_tree", "pmc_grbm_direct", "pmc_sq_walk16"):
     for r in rows(f"{sub}/**/*counter_collection.csv"):
-        a = pmc[sub][(short(r["Kernel_Name"]), r["Counter_Name"])]
+        kname = r["Kernel_Name"]
+        key = walk_name(kname) if sub == "pmc_sq_walk16" and "walk" in kname.split("(")[0] else short(kname)
+        a = pmc[sub][(key, r["Counter_Name"])]
         a[0] += 1; a[1] += float(r["Counter_Value"])
 with open(os.path.join(root, "profiles", f"{tag}_pmc.txt"), "w") as f:
     f.write(f"# rocprofv3 --pmc passes (one counter group per run), tag {tag}; value = mean per dispatch\n")
     for sub in sorted(pmc):
         f.write(f"\n[{sub}]\n")
         for (k, c), a in sorted(pmc[sub].items()):
-            f.write(f"{k:28s} {c:24s} dispatches {a[0]:6d}  mean {a[1] / a[0]:18.1f}\n")
+            f.write(f"{k:36s} {c:24s} dispatches {a[0]:6d}  mean {a[1] / a[0]:18.1f}\n")
 
 
 def mean(sub, kernel, counter):
