@@ -341,7 +341,8 @@ __global__ __launch_bounds__(WALK_BLOCK) void walk_kernel(
         if (!EVENTS && take) my_skip = skip;
         if (EVENTS && opening != 0) {
             // the cursor descends: the lanes that accept the cell sleep until the cursor reaches its end
-            const bool fin = r2 < FAR_TEST;
+            // (fp32: "!=" and not "<", so that the compiler forms one compare for the vote and for the select, not two)
+            const bool fin = __is_same(R, float) ? r2 != FAR : r2 < FAR_TEST;
             const bool rest = !open && fin;
             // (the vote on "somebody rests" from the masks of the plain compares: the ballot of a combined condition goes
             // through a vector register and back)
@@ -646,12 +647,11 @@ __global__ __launch_bounds__(WALK_BLOCK) void walk_pair_kernel(
         // (two ballots joined by a scalar OR: the ballot of "open0 || open1" goes through a vector register)
         // (the OR of the two votes sets the scalar condition code that picks the next node: written out, because the
         // compiler compares the mask with zero again and turns the verdict into a mask and back on the way to the request)
+        const unsigned long long votes0 = __builtin_amdgcn_ballot_w64(open0), votes1 = __builtin_amdgcn_ballot_w64(open1);
         unsigned long long opening;
         int next;
         asm("s_or_b64 %0, %2, %3\n\ts_cselect_b32 %1, %4, %5"
-            : "=&s"(opening), "=s"(next)
-            : "s"(__builtin_amdgcn_ballot_w64(open0)), "s"(__builtin_amdgcn_ballot_w64(open1)), "s"(cur + 1), "s"(skip)
-            : "scc");
+            : "=&s"(opening), "=s"(next) : "s"(votes0), "s"(votes1), "s"(cur + 1), "s"(skip) : "scc");
         float keep = r2.x;
         there = request_raw(nodes, next, keep);    // the force arithmetic below runs while this is in flight
         r2.x = keep;
@@ -663,10 +663,13 @@ __global__ __launch_bounds__(WALK_BLOCK) void walk_pair_kernel(
         }
         if (opening != 0) {
             // the cursor descends: the bodies that accept the cell sleep until the cursor reaches its end
-            const bool fin0 = r2.x < (float)INFINITY, fin1 = r2.y < (float)INFINITY;
+            // ("!=" and not "<": the compiler then forms one compare for the vote and for the selects, not two)
+            const bool fin0 = r2.x != (float)INFINITY, fin1 = r2.y != (float)INFINITY;
             const bool rest0 = !open0 && fin0, rest1 = !open1 && fin1;
-            // (taking this vote from the masks of the plain compares, as walk_kernel does, measured 0.5 % slower here)
-            if ((__builtin_amdgcn_ballot_w64(rest0) | __builtin_amdgcn_ballot_w64(rest1)) != 0) {
+            // (the vote from the masks of the plain compares: the ballot of a combined condition goes through a vector
+            // register and back)
+            const unsigned long long resting = (__builtin_amdgcn_ballot_w64(fin0) & ~votes0) | (__builtin_amdgcn_ballot_w64(fin1) & ~votes1);
+            if (resting != 0) {
                 if (rest0) { my_skip0 = skip; seed.x = (float)INFINITY; }
                 if (rest1) { my_skip1 = skip; seed.y = (float)INFINITY; }
                 // push the end of the cell around this one (a last child ends where its parent ends: one wake for both)
