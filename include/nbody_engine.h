@@ -192,8 +192,9 @@ int nbe_energy(nbe_engine *e, double *kinetic, double *potential, double momentu
  * The reference's only data-parallel strategy is to give each of 4 goroutines a contiguous quarter of the
  * bodies against a shared read-only tree (main.go:134-149); a shard is that quarter.
  *   nbe_set_shard(first, count)   targets [first, first+count) in device order belong to this engine (choose `first`
- *                                 as a multiple of 64: tree mode then matches a one-engine run bit for bit in every
- *                                 precision; otherwise NBE_PREC_MIXED differs in the last bits)
+ *                                 as a multiple of 256: tree mode then matches a one-engine run bit for bit in every
+ *                                 precision; otherwise NBE_PREC_MIXED, whose fp32 partial sums are flushed per
+ *                                 wavefront of 64 or 128 consecutive bodies, differs in the last bits)
  *   nbe_shard_sort                optional, tree mode: the part of the sort that reads positions only (keys, radix
  *                                 passes), so that it can run while the velocities of the other engines still arrive
  *   nbe_shard_prepare             tree mode: sort by Morton key, reorder state, build the tree (replicated)
@@ -357,7 +358,9 @@ int nbe_time_force_kernel(nbe_engine *e, int reps, float *ms_per_launch);
  * each GPU holds from the library's first use on it until the process ends; hence at most 262,144 bodies
  * (NBE_E_UNSUPPORTED beyond), and two calls that overlap in time on one GPU (different streams or threads) race on
  * that array: issue them on one stream, or one after the other.  No hipMalloc, hipFree or other allocating call is
- * made, on the device or the host.  Results equal nbe_accel's for the same bodies bit for bit when the masses are
+ * made, on the device or the host; the caller's current HIP device is the same after the call as before it.  The first
+ * call on a device looks the array's address up (hipGetSymbolAddress, which may load the code object): make that
+ * call outside graph capture; every later call on that device only queues kernels.  Results equal nbe_accel's for the same bodies bit for bit when the masses are
  * not all equal (nbe_accel switches to a kernel without the mass factor for equal masses: same values to rounding). */
 int nbe_accel_direct_noalloc(int device, void *hip_stream, size_t n, const float *d_pos_mass, float *d_acc, double G,
                              double eps);

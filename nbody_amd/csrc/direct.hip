@@ -393,7 +393,17 @@ extern "C" int nbe_accel_direct_noalloc(int device, void* hip_stream, size_t n, 
     }
     if (!(eps >= 0.0) || !std::isfinite(G)) { nbe_set_error("nbe_accel_direct_noalloc: eps must be >= 0 and G finite"); return NBE_E_INVALID; }
     if (device < 0 || device >= NOALLOC_MAX_DEVICES) { nbe_set_error("device %d out of range", device); return NBE_E_INVALID; }
-    NBE_HIP(hipSetDevice(device));
+    // the caller's current device is put back on every way out
+    struct DeviceGuard {
+        int prev = -1;
+        ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+    } guard;
+    int prev = -1;
+    NBE_HIP(hipGetDevice(&prev));
+    if (prev != device) {
+        NBE_HIP(hipSetDevice(device));
+        guard.prev = prev;
+    }
     float4* part = nullptr;
     NBE_TRY(scratch_for_device(device, &part));
     constexpr int ITILE = DIRECT_ITILE, BLOCK = 64;

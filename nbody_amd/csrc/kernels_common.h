@@ -11,9 +11,11 @@ __device__ __forceinline__ float rsq_dev(float x) { return __builtin_amdgcn_rsqf
 // (the fp64 parity tests hold at 1e-12 with one step as they did with two; the direct sum gains 14 %).
 __device__ __forceinline__ double rsq_dev(double x)
 {
-    double y = __builtin_amdgcn_rsq(x);
-    y = y * (1.5 - 0.5 * x * y * y);
-    return y;
+    // written with an explicit fma in the same shape as rsq2_dev below, so that "exactly half of rsq2_dev" does not
+    // depend on what the compiler contracts
+    const double y = __builtin_amdgcn_rsq(x);
+    const double t = x * y;
+    return y * fma(-(0.5 * t), y, 1.5);
 }
 
 // 2 / sqrt(x): the same Newton step written as y (3 - x y^2), which leaves out the halvings of y (1.5 - 0.5 x y^2):

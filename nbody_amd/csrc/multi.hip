@@ -47,7 +47,17 @@ struct Workers {
                         seen = generation;
                         f = job;
                     }
-                    const int rc = f(r);
+                    // a job allocates host vectors: an exception must not leave the thread (std::terminate)
+                    int rc;
+                    try {
+                        rc = f(r);
+                    } catch (const std::bad_alloc&) {
+                        nbe_set_error("out of host memory in the worker of GPU %d", r);
+                        rc = NBE_E_NOMEM;
+                    } catch (const std::exception& ex) {
+                        nbe_set_error("worker of GPU %d: %s", r, ex.what());
+                        rc = NBE_E_INVALID;
+                    }
                     {
                         std::lock_guard<std::mutex> lk(mu);
                         if (rc != NBE_OK && first_rc == NBE_OK) { first_rc = rc; first_msg = nbe_last_error(); }
@@ -141,6 +151,7 @@ struct MultiState {
     std::vector<hipStream_t> side;           // engine r: stream of its velocity copies (tree mode: they run beside the key sort)
     std::vector<hipEvent_t> vel_done;        // engine r: its velocity copies have landed (recorded on side[r])
     DistMulti* dist = nullptr;               // cfg.distributed: the bodies are not replicated
+    bool poisoned = false;                   // a step failed part-way: the GPUs may disagree about the state until the next upload
 };
 
 nbe_engine* multi_first(nbe_engine* e) { return e->multi->subs[0]; }
@@ -677,9 +688,27 @@ int multi_dist_stats(nbe_engine* e, nbe_stats_t* out)
     return NBE_OK;
 }
 
+// Waits for everything any GPU of the engine has queued: the engines' own streams and the side streams of the velocity
+// copies.  An upload frees and reallocates every engine's buffers, and hipFree waits for the owning GPU's streams only,
+// while the other GPUs' peer copies read those buffers from streams of their own.
+static int multi_quiesce(nbe_engine* e)
+{
+    MultiState* m = e->multi;
+    for (size_t r = 0; r < m->subs.size(); r++) {
+        if (m->subs[r]) NBE_TRY(nbe_sync(m->subs[r]));
+        if (r < m->side.size() && m->side[r]) {
+            NBE_HIP(hipSetDevice(m->devs[r]));
+            NBE_HIP(hipStreamSynchronize(m->side[r]));
+        }
+    }
+    return NBE_OK;
+}
+
 int multi_upload(nbe_engine* e, size_t n, const double* pos, const double* vel, const double* mass, const uint64_t* id)
 {
     MultiState* m = e->multi;
+    NBE_TRY(multi_quiesce(e));
+    m->poisoned = false;
     if (m->dist) return dist_upload(e, n, pos, vel, mass, id);
     const size_t G = m->subs.size();
     ranges(n, G, &m->first, &m->count);
@@ -704,12 +733,25 @@ int multi_sync(nbe_engine* e)
     return NBE_OK;
 }
 
+static int multi_step_replicated(nbe_engine* e, int nsteps);
+
 int multi_step(nbe_engine* e, int nsteps)
 {
     MultiState* m = e->multi;
-    const size_t G = m->subs.size();
+    if (m->poisoned) {
+        nbe_set_error("an earlier nbe_step failed part-way and the GPUs may hold different states: upload again");
+        return NBE_E_INVALID;
+    }
     if (e->n == 0) return NBE_OK;
-    if (m->dist) return dist_step(e, nsteps);
+    const int rc = m->dist ? dist_step(e, nsteps) : multi_step_replicated(e, nsteps);
+    if (rc != NBE_OK) m->poisoned = true;
+    return rc;
+}
+
+static int multi_step_replicated(nbe_engine* e, int nsteps)
+{
+    MultiState* m = e->multi;
+    const size_t G = m->subs.size();
     for (int step = 0; step < nsteps; step++) {
         // sort + build on every GPU (replicated, identical results); also sends the frame of this step from GPU 0
         for (size_t r = 0; r < G; r++) NBE_TRY(nbe_shard_prepare(m->subs[r]));

@@ -335,6 +335,28 @@ def test_engine_driving_several_shards_itself(gpu, mode, precision, extra):
         assert np.abs(got[1] - want[1]).max() <= 1e-5 * np.abs(want[1]).max()
 
 
+@pytest.mark.parametrize("distributed", [False, True])
+def test_upload_right_after_a_step_of_a_several_shard_engine(gpu, distributed):
+    """nbe_step returns without waiting; an upload that follows at once frees and reallocates every shard's buffers
+    while the other shards' copies may still read them, so the upload has to wait for all shards first.  Step, upload
+    other bodies, step, with no synchronisation in between: the second scene must come out as from a fresh engine."""
+    b1 = physics.plummer(30001, seed=21, a=2e3)
+    b2 = physics.plummer(20001, seed=22, a=2e3)
+    kw = dict(tree_sums=True) if distributed else {}
+    with Engine(mode="tree", precision="f32", theta=0.6, **kw) as one:
+        one.upload(b2.pos, b2.vel, b2.mass)
+        one.step(3)
+        want = one.download()
+    with Engine(mode="tree", precision="f32", theta=0.6, devices=[0, 0, 0], distributed=distributed) as e:
+        e.upload(b1.pos, b1.vel, b1.mass)
+        e.step(3)
+        e.upload(b2.pos, b2.vel, b2.mass)
+        e.step(3)
+        got = e.download()
+    for a, w in zip(got, want):
+        assert np.array_equal(a, w)
+
+
 def test_two_engines_in_one_process_do_not_share_state(gpu):
     """Engines own their streams and workspaces: two of them stepped in turn give what each gives alone."""
     b1 = physics.makebodies(1500, seed=1); b2 = physics.plummer(2500, seed=2)

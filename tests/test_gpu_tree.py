@@ -364,6 +364,29 @@ def test_walk_with_two_bodies_per_lane_equals_one_body_per_lane(gpu, monkeypatch
             assert np.array_equal(a, c, equal_nan=True)
 
 
+def test_walk_with_two_bodies_per_lane_where_it_is_chosen_by_itself(gpu, monkeypatch):
+    """At 4,194,304 bodies the fp32 step picks the two-bodies-per-lane walk on its own (from 3M bodies of a launch).  Two
+    fused steps with the default choice against two with one body per lane forced: positions and velocities bit for bit,
+    i.e. the production variant of the kernel at a size where it is the production path."""
+    n = 1 << 22
+    b = physics.plummer(n, seed=11)
+    pos, mass = f32(b.pos), f32(b.mass)
+    out = []
+    for knob in (None, "1"):
+        if knob is None:
+            monkeypatch.delenv("NBODY_WALK_BODIES_PER_LANE", raising=False)
+        else:
+            monkeypatch.setenv("NBODY_WALK_BODIES_PER_LANE", knob)
+        with Engine(mode="tree", precision="f32", theta=0.5) as e:
+            e.upload(pos, b.vel, mass)
+            e.step(2)
+            p, v, m, ids = e.download()
+            out.append((p, v, ids))
+    assert len(out[0][0]) == n
+    for a, c in zip(out[0], out[1]):
+        assert np.array_equal(a, c)
+
+
 @pytest.mark.parametrize("n", [2, 65, 129, 1000, 8193, 50001, 300000])
 def test_mixed_walk_with_two_bodies_per_lane_agrees_with_one_body_per_lane(gpu, monkeypatch, n):
     """Mixed precision has the same two kernels.  Its fp32 partial sums join the fp64 totals every 64 visits of the

@@ -1,4 +1,5 @@
-"""nbe_accel_direct_noalloc, the force pass that allocates nothing, against nbe_accel of an engine.
+"""nbe_accel_direct_noalloc, the force pass that allocates nothing, against nbe_accel of an engine and against the
+CPU restatement of the reference's direct loop (main.go:105-128; parity unpinned: the reference holds no fixtures).
 
 Named so that pytest collects it after every other test file: a failure here must not hide the others behind -x."""
 import ctypes as C
@@ -7,6 +8,8 @@ import numpy as np
 import pytest
 
 from nbody_amd import Engine, engine as E, physics
+from oracle import oracle as O
+from tests.util import f32, relerr
 
 pytestmark = pytest.mark.gpu
 
@@ -40,6 +43,35 @@ def test_no_alloc_force_pass_equals_nbe_accel_on_two_calls_in_a_row(gpu):
         got = acc.cpu().numpy()
         assert np.isfinite(got).all() and not got[:, 3].any()
         assert np.array_equal(got[:, :3], want), np.abs(got[:, :3] - want).max()
+        # and against the CPU direct sum on the fp32-rounded inputs (the smaller scene in full, a sample of the larger)
+        pos32, m32 = f32(b.pos), f32(b.mass)
+        rows = np.arange(n) if n <= 4096 else np.arange(0, n, n // 512)[:512]
+        ref = np.concatenate([O.direct_rows(m32, pos32, t0=int(t), t1=int(t) + 1, eps=eps, nthreads=1) for t in rows])
+        ref = ref / m32[rows][:, None]
+        er = relerr(got[rows, :3].astype(np.float64), ref)
+        assert np.median(er) <= 1e-6 and np.quantile(er, 0.999) <= 1e-4, (np.median(er), er.max())
+
+
+def test_no_alloc_force_pass_leaves_the_callers_device_current(gpu):
+    """The entry point makes `device` current for its launches and must put the caller's device back."""
+    import torch
+    lib = E.load_library()
+    hip = C.CDLL("libamdhip64.so")
+    before = C.c_int(-1)
+    assert hip.hipGetDevice(C.byref(before)) == 0
+    t = torch.ones(64, 4, dtype=torch.float32, device="cuda:0")
+    out = torch.empty_like(t)
+    ndev = torch.cuda.device_count()
+    if ndev > 1:                                  # make another device current: the call must switch back to it
+        assert hip.hipSetDevice(1) == 0
+        before = C.c_int(1)
+    assert lib.nbe_accel_direct_noalloc(0, None, 64, C.c_void_p(t.data_ptr()), C.c_void_p(out.data_ptr()), 1.0, 1.0) == 0
+    after = C.c_int(-2)
+    assert hip.hipGetDevice(C.byref(after)) == 0
+    assert after.value == before.value
+    if ndev > 1:
+        assert hip.hipSetDevice(0) == 0
+    torch.cuda.synchronize()
 
 
 def test_no_alloc_force_pass_rejects_what_does_not_fit(gpu):
