@@ -53,7 +53,7 @@ typedef struct {
     int reference_quirks;   /* tree mode: bit set of NBE_QUIRK_*; 0 = physically meant behaviour */
     int walk_criterion;     /* tree mode: NBE_WALK_PER_BODY (the reference's test, default) or NBE_WALK_PER_WAVE */
     int num_devices;        /* 0 or 1: one GPU, `device`.  G > 1: the engine drives G GPUs from this process, see below */
-    int cell_sums;          /* tree mode, fp32 node records: NBE_SUMS_PREFIX (default) or NBE_SUMS_TREE, see below */
+    int cell_sums;          /* tree mode: NBE_SUMS_PREFIX (default), NBE_SUMS_TREE or NBE_SUMS_EXACT, see below */
     const int *device_ids;  /* num_devices HIP device ordinals (copied by nbe_create); NULL = devices 0 .. G-1 */
     int distributed;        /* with num_devices > 1 in tree mode: 1 = every body lives on one GPU only and the GPUs exchange
                                pruned subtrees (the key-range-distributed tree, nbe_dist_* below, driven by the engine itself) */
@@ -75,16 +75,21 @@ typedef struct {
  * GPU, with peer copies for the exchanges.  nbe_upload, nbe_step, nbe_download, nbe_stats, nbe_energy (tree potential),
  * nbe_sync and the frame stream work (no GPU holds all bodies: every GPU snapshots its own before the step and sends
  * them into its stretch of the frame's pinned buffer on a stream of its own; the rows of a frame are in key order);
- * results equal those of one GPU with cell_sums = NBE_SUMS_TREE bit for bit in fp32 and fp64; the other calls are refused. */
+ * results equal those of one GPU with cell_sums = NBE_SUMS_EXACT bit for bit in fp32 and fp64; the other calls are refused. */
 
 /* How a cell's mass and centre of mass are summed (fp64 either way).
  *   NBE_SUMS_PREFIX   differences of prefix sums over the Morton-sorted bodies: three launches, the fastest, and the
  *                     rounding of a cell's sums depends on everything sorted before it.  fp32 node records only
- *                     (the error stays below their rounding); fp64 node records always use NBE_SUMS_TREE.
- *   NBE_SUMS_TREE     every cell adds up its children in octant order, bodies as they stand: a cell's sums depend on
- *                     nothing outside it, so trees built from any partition of the bodies carry the same bits.  This is
- *                     what the key-range-distributed build (nbe_dist_*) uses. */
-enum { NBE_SUMS_PREFIX = 0, NBE_SUMS_TREE = 1 };
+ *                     (the error stays below their rounding); fp64 node records use NBE_SUMS_EXACT instead.
+ *   NBE_SUMS_TREE     every cell adds up its children in octant order, bodies as they stand (fp64): a cell's sums depend
+ *                     on nothing outside it; one launch per tree depth.
+ *   NBE_SUMS_EXACT    every body's (m, m*x, m*y, m*z) is cut to a multiple of a quantum fixed for the run (2^-126 of the
+ *                     total mass times the bound's reach) and summed as 128-bit integers; cells take differences of the
+ *                     prefix sums (three launches, like NBE_SUMS_PREFIX).  Integer sums do not depend on the order of
+ *                     addition, so trees built from any partition of the bodies carry the same bits: this is what the
+ *                     key-range-distributed build (nbe_dist_*) uses, and one engine with this setting is what its results
+ *                     equal bit for bit.  Works for fp32 and fp64 node records. */
+enum { NBE_SUMS_PREFIX = 0, NBE_SUMS_TREE = 1, NBE_SUMS_EXACT = 2 };
 
 /* Who decides whether a cell is opened (tree.go:216-217, edge / distance > theta).
  *   NBE_WALK_PER_BODY   every body for itself, as the reference's recursion does: each body receives exactly the
@@ -225,14 +230,14 @@ int nbe_device_state(nbe_engine *e, nbe_device_state_t *out);
  *     migration records / nbe_dist_receive).
  *   * Every rank sorts its own bodies and builds the octree over them (nbe_dist_build).  A subtree whose cell lies
  *     wholly inside the rank's key range is exactly that subtree of the global octree (a "fragment"); the few cells
- *     above the fragments, which span ranks, are rebuilt on every rank from the fragments' roots (key, depth, fp64
- *     sums), all-gathered by the caller.  Cell sums are NBE_SUMS_TREE, so they carry the bits of a one-engine build.
+ *     above the fragments, which span ranks, are rebuilt on every rank from the fragments' roots (key, depth, exact
+ *     sums), all-gathered by the caller.  Cell sums are NBE_SUMS_EXACT, so they carry the bits of a one-engine build.
  *   * For every other rank q, nbe_dist_export prunes each fragment to the nodes some body of q could visit (cells whose
  *     opening test no point of q's bounding box can pass are cut below), in pre-order with skip pointers; the caller
  *     moves these records (all-to-all), and nbe_dist_assemble lays out the rank's own fragments, the imported ones and
  *     the spanning cells as one pre-order node array.  The walk kernel then runs on it unchanged (nbe_dist_advance):
  *     every body visits exactly the nodes it visits in the one-engine tree, in the same order, so fp32 and fp64 runs
- *     equal a one-engine run with cell_sums = NBE_SUMS_TREE bit for bit (NBE_PREC_MIXED to rounding: its partial sums
+ *     equal a one-engine run with cell_sums = NBE_SUMS_EXACT bit for bit (NBE_PREC_MIXED to rounding: its partial sums
  *     are flushed by wavefront, and the wavefronts hold other bodies).
  *     (Bodies that share all 63 key bits, i.e. lie in the same 3 cm cell of the reference's bound, are ordered by their
  *     upload index on one engine and by their run-wide index here, in runs of up to 64 such bodies, so they too are
@@ -246,7 +251,8 @@ typedef struct {
     int32_t start;          /* pre-order index of the root in the owner's node array */
     int32_t nodes;          /* nodes of the subtree */
     int32_t reserved;
-    double sum[4];          /* fp64 mass, sum m*x, sum m*y, sum m*z of the fragment */
+    uint64_t sum[8];        /* exact sums of the fragment's bodies (NBE_SUMS_EXACT): mass, m*x, m*y, m*z as 128-bit two's
+                               complement integers, low word first, in the run's quanta */
 } nbe_fragment_t;
 
 typedef struct {
@@ -268,6 +274,9 @@ int nbe_dist_upload(nbe_engine *e, int rank, int world, size_t capacity, size_t 
 /* Up to max_samples evenly spaced keys of the rank's bodies in sorted order (for choosing splitters); *n_live = bodies
  * inside the bound. */
 int nbe_dist_sample_keys(nbe_engine *e, size_t max_samples, uint64_t *keys_out, size_t *count, size_t *n_live);
+/* The total mass of the run's bodies (all ranks), the same value on every rank: it fixes the quantum of the exact cell sums
+ * (NBE_SUMS_EXACT).  Needed once, before the first nbe_dist_build; an upper bound will do. */
+int nbe_dist_set_total_mass(nbe_engine *e, double total_mass);
 /* split[0] = 0 <= split[1] <= ... <= split[world] = 2^63: rank r owns keys in [split[r], split[r+1]). */
 int nbe_dist_set_splitters(nbe_engine *e, const uint64_t *split);
 int nbe_dist_buffers(nbe_engine *e, nbe_dist_buffers_t *out);
@@ -292,11 +301,10 @@ int nbe_dist_export(nbe_engine *e, const nbe_fragment_t *all_frags, const int *f
 int nbe_dist_assemble(nbe_engine *e, const int32_t *import_sizes, const uint64_t *import_offsets);
 /* The host-side half of nbe_dist_assemble on its own (needs no GPU and no engine; for tests of the stitching): given the
  * fragments of all ranks in key order and the number of nodes each occupies, lays out the global pre-order.  tops receives
- * the cells that span fragments (first index, index after the subtree, depth, fp64 sums of the children added in octant
- * order), frag_dst the first index of every fragment, *total the number of nodes. */
+ * the cells that span fragments (first index, index after the subtree, depth, exact sums of the fragments below), frag_dst the first index of every fragment, *total the number of nodes. */
 typedef struct {
     int32_t dst, skip, level, reserved;
-    double sum[4];
+    uint64_t sum[8];        /* as nbe_fragment_t.sum: the sums of the fragments below, added as integers */
 } nbe_dist_top_cell_t;
 int nbe_dist_layout(const nbe_fragment_t *all_frags, int nfrags, const int32_t *sizes, nbe_dist_top_cell_t *tops, int max_tops,
                     int *ntops, int32_t *frag_dst, int64_t *total);

@@ -20,6 +20,7 @@
 #include "engine_internal.h"
 #include "kernels_common.h"
 #include "tree_keys.h"
+#include "tree_sums.h"
 
 #include <algorithm>
 #include <cmath>
@@ -36,8 +37,8 @@ struct Segment {          // one fragment in the assembled node array
 };
 
 struct TopCell {          // a cell that spans ranks
-    int dst, skip, level;
-    double sum[4];
+    int dst, skip, level, pad;
+    Q4 sum;               // exact sums of its bodies (tree_sums.h)
 };
 
 #define BOX_PARTS 128     // workgroups that share the bodies of one fragment
@@ -57,7 +58,7 @@ struct DistState {
     uint32_t* free_slots = nullptr;     // slots vacated by the last classify
     uint32_t n_free = 0;
     int frag_hint = 0;                  // fragments of the last build (sizes the grid of the next build's box kernel)
-    bool classified = false, built = false, exported = false, assembled = false;
+    bool classified = false, built = false, exported = false, assembled = false, have_total = false;
     // fragments of the last build
     nbe_fragment_t* d_frags = nullptr;
     int* d_nfrag = nullptr;             // [0] count, [1] overflow flag of the export buffer
@@ -164,7 +165,7 @@ extern "C" int nbe_dist_upload(nbe_engine* e, int rank, int world, size_t capaci
     DistState* d = new (std::nothrow) DistState();
     if (!d) { nbe_set_error("out of host memory"); return NBE_E_NOMEM; }
     e->dist = d;
-    e->cfg.cell_sums = NBE_SUMS_TREE;
+    e->cfg.cell_sums = NBE_SUMS_EXACT;                // sums that do not depend on the partition of the bodies
     e->tw.cap = 0;                                   // the tree workspace is laid out anew (sums by tree, scans over nodes)
     d->rank = rank; d->world = world; d->cap = capacity; d->live_hi = n;
     // free slots hold massless bodies parked outside the bound: the sort sends them behind the live ones
@@ -307,6 +308,16 @@ extern "C" int nbe_dist_set_splitters(nbe_engine* e, const uint64_t* split)
     d->split.assign(split, split + d->world + 1);
     NBE_HIP(hipMemcpyAsync(d->d_split, d->split.data(), (d->world + 1) * 8, hipMemcpyHostToDevice, e->stream));
     NBE_HIP(hipStreamSynchronize(e->stream));
+    return NBE_OK;
+}
+
+extern "C" int nbe_dist_set_total_mass(nbe_engine* e, double total_mass)
+{
+    NBE_TRY(check_dist(e, "nbe_dist_set_total_mass"));
+    if (!(total_mass >= 0.0) || !std::isfinite(total_mass)) { nbe_set_error("total_mass must be finite and >= 0"); return NBE_E_INVALID; }
+    // (fp32 state holds rounded masses: a little headroom covers their sum)
+    tree_set_total_mass(e, total_mass * (1.0 + 0x1p-20));
+    e->dist->have_total = true;
     return NBE_OK;
 }
 
@@ -502,7 +513,7 @@ __device__ __forceinline__ bool cell_inside(uint64_t key, int level, uint64_t lo
 
 // A node roots a fragment iff its cell is inside the rank's key range and the cell of the node above is not.
 __global__ __launch_bounds__(256) void fragments_kernel(const CNode* __restrict__ cn, const int* __restrict__ counters,
-                                                        const double* __restrict__ node_sum, uint64_t lo, uint64_t hi,
+                                                        const Q4* __restrict__ prefixq, uint64_t lo, uint64_t hi,
                                                         nbe_fragment_t* __restrict__ frags, int* __restrict__ nfrag,
                                                         int* __restrict__ frag_bodies)
 {
@@ -521,14 +532,18 @@ __global__ __launch_bounds__(256) void fragments_kernel(const CNode* __restrict_
     f.start = p;
     f.nodes = c.skip - p;
     f.reserved = at;                                  // its place in this (unordered) list: where its box will be
-    for (int k = 0; k < 4; k++) f.sum[k] = node_sum[4 * (size_t)p + k];
-    frags[at] = f;
     // its bodies: in pre-order the first children of the cells below follow the root one by one down to the first leaf,
     // and the last node of the subtree is its last leaf
     int first = p;
     while (cn[first].body < 0) first++;
-    frag_bodies[2 * at] = cn[first].body;
-    frag_bodies[2 * at + 1] = cn[c.skip - 1].body + 1;
+    const int b0 = cn[first].body, b1 = cn[c.skip - 1].body + 1;
+    frag_bodies[2 * at] = b0;
+    frag_bodies[2 * at + 1] = b1;
+    // its exact sums: a difference of the prefix sums over its (consecutive) bodies
+    const Q4 q = q4_sub(prefixq[b1], prefixq[b0]);
+    f.sum[0] = q.m.lo; f.sum[1] = q.m.hi; f.sum[2] = q.x.lo; f.sum[3] = q.x.hi;
+    f.sum[4] = q.y.lo; f.sum[5] = q.y.hi; f.sum[6] = q.z.lo; f.sum[7] = q.z.hi;
+    frags[at] = f;
 }
 
 // Box of the bodies of every fragment: BOX_PARTS workgroups share a fragment's bodies, then one thread per fragment and
@@ -633,6 +648,7 @@ extern "C" int nbe_dist_build(nbe_engine* e, nbe_fragment_t* frags, int max, int
     NBE_TRY(check_dist(e, "nbe_dist_build"));
     DistState* d = e->dist;
     if (!frags || !count || !boxes || !nboxes) { nbe_set_error("NULL argument"); return NBE_E_INVALID; }
+    if (!d->have_total) { nbe_set_error("nbe_dist_build before nbe_dist_set_total_mass"); return NBE_E_INVALID; }
     e->keys_sorted = false;
     // Only the slots that can hold bodies take part: the engine's body count is the number of those (its buffers keep
     // their capacity), so the sort, the build and the walk do not pay for the free slots behind them.
@@ -647,7 +663,7 @@ extern "C" int nbe_dist_build(nbe_engine* e, nbe_fragment_t* frags, int max, int
         NBE_TRY(tree_sort_and_build(e));
         NBE_TRY(collide_emit_geometry(e));
         hipLaunchKernelGGL(fragments_kernel, dim3(cdiv(2 * e->n, 256)), dim3(256), 0, e->stream, e->cw.cnodes, e->tw.counters,
-                           e->tw.node_sum, d->split[d->rank], d->split[d->rank + 1], d->d_frags, d->d_nfrag, d->d_frag_bodies);
+                           (const Q4*)e->tw.prefixq, d->split[d->rank], d->split[d->rank + 1], d->d_frags, d->d_nfrag, d->d_frag_bodies);
         NBE_TRY(fragment_boxes(e, box_rows));
     }
     NBE_HIP(hipGetLastError());
@@ -976,7 +992,7 @@ extern "C" int nbe_dist_export(nbe_engine* e, const nbe_fragment_t* all_frags, c
 }
 
 // ---- the cells above the fragments, and the layout of the assembled array ---------------------------------------------------
-struct FragRef { uint64_t key; int rank, idx, size; const double* sum; };
+struct FragRef { uint64_t key; int rank, idx, size; const uint64_t* sum; };
 
 struct Layout {
     std::vector<Segment> segs;
@@ -985,35 +1001,38 @@ struct Layout {
 };
 
 // Lays out fragments [i, j), which share a cell, in pre-order from index `at`; returns the number of nodes and leaves the
-// fp64 sums of what it laid out in `sum`.  A cell sums its children in octant order starting from zero, as cell_mass_kernel.
-static int layout_range(const std::vector<FragRef>& fr, int i, int j, int at, const std::vector<Segment>& seg_of, Layout* out, double sum[4])
+// exact sums of what it laid out in `sum` (128-bit integers: the order of addition does not matter).
+static Q4 q4_from_words(const uint64_t* w) { return Q4{{w[0], w[1]}, {w[2], w[3]}, {w[4], w[5]}, {w[6], w[7]}}; }
+
+static int layout_range(const std::vector<FragRef>& fr, int i, int j, int at, const std::vector<Segment>& seg_of, Layout* out, Q4* sum)
 {
     if (j - i == 1) {
         Segment s = seg_of[(size_t)i];
         s.dst = at;
         s.rebase += at;
         out->segs.push_back(s);
-        for (int k = 0; k < 4; k++) sum[k] = fr[(size_t)i].sum[k];
+        *sum = q4_from_words(fr[(size_t)i].sum);
         return s.count;
     }
     const int L = common_level(fr[(size_t)i].key, fr[(size_t)j - 1].key);
     const size_t me = out->tops.size();
-    out->tops.push_back(TopCell{at, 0, L, {0, 0, 0, 0}});
+    out->tops.push_back(TopCell{at, 0, L, 0, q4_zero()});
     int n = 1;
-    double acc[4] = {0, 0, 0, 0};
+    Q4 acc = q4_zero();
     int a = i;
     while (a < j) {
         const unsigned digit = L >= 21 ? 0u : (unsigned)(fr[(size_t)a].key >> (3 * (20 - L))) & 7u;
         int b = a + 1;
         while (b < j && L < 21 && ((unsigned)(fr[(size_t)b].key >> (3 * (20 - L))) & 7u) == digit) b++;
-        double cs[4];
-        n += layout_range(fr, a, b, at + n, seg_of, out, cs);
-        for (int k = 0; k < 4; k++) acc[k] += cs[k];
+        Q4 cs;
+        n += layout_range(fr, a, b, at + n, seg_of, out, &cs);
+        acc = q4_add(acc, cs);
         a = b;
     }
     TopCell& t = out->tops[me];
     t.skip = at + n;
-    for (int k = 0; k < 4; k++) { t.sum[k] = acc[k]; sum[k] = acc[k]; }
+    t.sum = acc;
+    *sum = acc;
     return n;
 }
 
@@ -1030,14 +1049,16 @@ extern "C" int nbe_dist_layout(const nbe_fragment_t* all_frags, int nfrags, cons
         seg_of.push_back(Segment{0, sizes[g], g, 0, 0});          // src carries the fragment's number
     }
     Layout lay;
-    double sum[4];
-    if (!fr.empty()) lay.total = layout_range(fr, 0, nfrags, 0, seg_of, &lay, sum);
+    Q4 sum;
+    if (!fr.empty()) lay.total = layout_range(fr, 0, nfrags, 0, seg_of, &lay, &sum);
     *total = lay.total;
     *ntops = (int)lay.tops.size();
     if ((int)lay.tops.size() > max_tops && tops) { nbe_set_error("%zu spanning cells, room for %d", lay.tops.size(), max_tops); return NBE_E_INVALID; }
     for (size_t t = 0; tops && t < lay.tops.size(); t++) {
         tops[t].dst = lay.tops[t].dst; tops[t].skip = lay.tops[t].skip; tops[t].level = lay.tops[t].level; tops[t].reserved = 0;
-        for (int k = 0; k < 4; k++) tops[t].sum[k] = lay.tops[t].sum[k];
+        const Q4& q = lay.tops[t].sum;
+        const uint64_t w[8] = {q.m.lo, q.m.hi, q.x.lo, q.x.hi, q.y.lo, q.y.hi, q.z.lo, q.z.hi};
+        for (int k = 0; k < 8; k++) tops[t].sum[k] = w[k];
     }
     if (frag_dst)
         for (const Segment& s : lay.segs) frag_dst[s.src] = s.dst;
@@ -1046,7 +1067,7 @@ extern "C" int nbe_dist_layout(const nbe_fragment_t* all_frags, int nfrags, cons
 
 template <typename NodeT>
 __global__ __launch_bounds__(256) void top_cells_kernel(const TopCell* __restrict__ tops, int ntops, double bound_width, double theta,
-                                                        double eps2, int total, NodeT* __restrict__ out)
+                                                        double eps2, int total, int shift_m, int shift_x, NodeT* __restrict__ out)
 {
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t == 0) {
@@ -1060,9 +1081,7 @@ __global__ __launch_bounds__(256) void top_cells_kernel(const TopCell* __restric
     if (t >= ntops) return;
     const TopCell c = tops[t];
     NodeT nd;
-    const double m = c.sum[0];
-    const double inv = m != 0.0 ? 1.0 / m : 0.0;
-    nd.x = c.sum[1] * inv; nd.y = c.sum[2] * inv; nd.z = c.sum[3] * inv; nd.m = m;
+    exact_cell(c.sum, shift_m, shift_x, nd);          // the expressions of the build's own cells
     set_edge<NodeT>(nd, bound_width * (1.0 / (double)(1u << c.level)), theta, eps2);
     nd.skip = c.skip;
     out[c.dst] = nd;
@@ -1120,8 +1139,8 @@ extern "C" int nbe_dist_assemble(nbe_engine* e, const int32_t* import_sizes, con
         }
     }
     Layout lay;
-    double sum[4];
-    if (!fr.empty()) lay.total = layout_range(fr, 0, (int)fr.size(), 0, seg_of, &lay, sum);
+    Q4 sum;
+    if (!fr.empty()) lay.total = layout_range(fr, 0, (int)fr.size(), 0, seg_of, &lay, &sum);
     if ((size_t)lay.total > d->let_cap) { nbe_set_error("rank %d: the assembled tree (%d nodes) exceeds the buffer (%zu)", d->rank, lay.total, d->let_cap); return NBE_E_NOMEM; }
     if (lay.segs.size() > d->seg_cap || lay.tops.size() > d->top_cap) { nbe_set_error("too many fragments"); return NBE_E_UNSUPPORTED; }
     // work items: the nodes of all segments, numbered segment after segment
@@ -1140,14 +1159,14 @@ extern "C" int nbe_dist_assemble(nbe_engine* e, const int32_t* import_sizes, con
     const int ntops = (int)lay.tops.size();
     if (e->force64) {
         hipLaunchKernelGGL((top_cells_kernel<NodeD>), dim3(cdiv(ntops + 1, 256)), dim3(256), 0, e->stream, d->d_top, ntops, e->cfg.bound_width,
-                           e->cfg.theta, eps2, lay.total, (NodeD*)d->let_nodes);
+                           e->cfg.theta, eps2, lay.total, e->tw.q_shift_m, e->tw.q_shift_x, (NodeD*)d->let_nodes);
         if (work > 0)
             hipLaunchKernelGGL((assemble_kernel<NodeD>), dim3(cdiv((size_t)work, 256)), dim3(256), 0, e->stream, d->d_segments,
                                (int)lay.segs.size(), d_seg_first, (const NodeD*)e->tw.nodes, (const NodeD*)d->import_nodes, work,
                                (NodeD*)d->let_nodes);
     } else {
         hipLaunchKernelGGL((top_cells_kernel<NodeF>), dim3(cdiv(ntops + 1, 256)), dim3(256), 0, e->stream, d->d_top, ntops, e->cfg.bound_width,
-                           e->cfg.theta, eps2, lay.total, (NodeF*)d->let_nodes);
+                           e->cfg.theta, eps2, lay.total, e->tw.q_shift_m, e->tw.q_shift_x, (NodeF*)d->let_nodes);
         if (work > 0)
             hipLaunchKernelGGL((assemble_kernel<NodeF>), dim3(cdiv((size_t)work, 256)), dim3(256), 0, e->stream, d->d_segments,
                                (int)lay.segs.size(), d_seg_first, (const NodeF*)e->tw.nodes, (const NodeF*)d->import_nodes, work,

@@ -86,8 +86,8 @@ extern "C" int nbe_create(const nbe_config* cfg, nbe_engine** out)
     if (cfg->reference_quirks && cfg->mode != NBE_MODE_TREE) { nbe_set_error("reference_quirks apply to tree mode only"); return NBE_E_INVALID; }
     if (cfg->num_devices < 0) { nbe_set_error("num_devices < 0"); return NBE_E_INVALID; }
     if (cfg->distributed != 0 && cfg->distributed != 1) { nbe_set_error("distributed must be 0 or 1"); return NBE_E_INVALID; }
-    if (cfg->distributed && cfg->num_devices <= 1) { nbe_set_error("distributed = 1 needs num_devices > 1 (one GPU: use cell_sums = NBE_SUMS_TREE for the same results)"); return NBE_E_INVALID; }
-    if (cfg->cell_sums != NBE_SUMS_PREFIX && cfg->cell_sums != NBE_SUMS_TREE) { nbe_set_error("bad cell_sums %d", cfg->cell_sums); return NBE_E_INVALID; }
+    if (cfg->distributed && cfg->num_devices <= 1) { nbe_set_error("distributed = 1 needs num_devices > 1 (one GPU: use cell_sums = NBE_SUMS_EXACT for the same results)"); return NBE_E_INVALID; }
+    if (cfg->cell_sums != NBE_SUMS_PREFIX && cfg->cell_sums != NBE_SUMS_TREE && cfg->cell_sums != NBE_SUMS_EXACT) { nbe_set_error("bad cell_sums %d", cfg->cell_sums); return NBE_E_INVALID; }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
         nbe_set_error("no HIP device available (this library has no CPU path)");
@@ -153,7 +153,7 @@ extern "C" void nbe_destroy(nbe_engine* e)
     TreeWork& w = e->tw;
     void* ptrs[] = {w.keys[0], w.keys[1], w.sidx[0], w.sidx[1], w.block_hist, w.scan_tmp, w.bt_first, w.bt_last, w.bt_parent,
                     w.bt_level, w.bt_cell, w.lvlmask, w.cellcnt, w.nodes, w.node_level, w.node_sum, w.counters, w.d_interactions,
-                    w.prefix, w.prefix_tiles, e->d_energy};
+                    w.prefix, w.prefix_tiles, w.prefixq, w.prefixq_tiles, e->d_energy};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (int k = 0; k < 5; k++)
@@ -217,6 +217,13 @@ int engine_upload_state(nbe_engine* e, size_t n, const double* pos, const double
         for (size_t i = 1; i < n && same; i++) same = mass[i] == mass[0];
         const double held = e->cfg.precision == NBE_PREC_F64 ? mass[0] : (double)(float)mass[0];
         if (same && held > 0.0 && std::isfinite(held)) e->equal_mass = held;
+    }
+    // the quanta of exact cell sums (NBE_SUMS_EXACT) follow from the total mass, which collisions keep and bodies that
+    // leave the bound only lower (fp32 state holds rounded masses: a little headroom covers their sum)
+    {
+        double total = 0.0;
+        for (size_t i = 0; i < n; i++) total += mass[i];
+        tree_set_total_mass(e, total * (1.0 + 0x1p-20));
     }
     const size_t cap = n > 0 ? n : 1;
     for (int b = 0; b < 2; b++) {

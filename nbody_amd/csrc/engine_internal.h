@@ -74,6 +74,10 @@ struct TreeWork {
     double* node_sum = nullptr;     // per pre-order node: fp64 (mass, m*x, m*y, m*z)  (fp64 node records only)
     double* prefix = nullptr;       // fp32 node records: fp64 prefix sums of (m, m*x, m*y, m*z) over sorted bodies
     double* prefix_tiles = nullptr;
+    void* prefixq = nullptr;        // NBE_SUMS_EXACT: 128-bit fixed-point prefix sums (64 bytes per body) and their tile totals
+    void* prefixq_tiles = nullptr;
+    int q_shift_m = 0, q_shift_x = 0;   // their quanta: 2^-q_shift_m (mass) and 2^-q_shift_x (mass x coordinate)
+    double total_mass = 0.0;        // what the quanta were chosen from
     int* counters = nullptr;        // device scalars: [0] n_alive, [1] total nodes, [2] branching cells
     unsigned long long* d_interactions = nullptr;
 };
@@ -221,6 +225,8 @@ int direct_forces(nbe_engine* e, int src_buf, uint64_t t0, uint64_t t1, bool fus
 // tree_build.hip
 int tree_workspace_reserve(nbe_engine* e);
 int tree_small_limit(void);
+int tree_sum_mode(const nbe_engine* e);         // NBE_SUMS_* in effect (fp64 node records: never the fp64 prefix differences)
+void tree_set_total_mass(nbe_engine* e, double total);   // quanta of NBE_SUMS_EXACT from the run's total mass
 int tree_sort_keys(nbe_engine* e);              // optional first half of tree_sort_and_build (reads positions only)
 int tree_sort_and_build(nbe_engine* e);         // sorts cur -> cur^1, flips e->cur, builds the tree
 int device_scan_u32(nbe_engine* e, const uint32_t* in, uint32_t* out, size_t len);

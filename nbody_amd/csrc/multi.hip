@@ -324,9 +324,12 @@ static int dist_upload(nbe_engine* e, size_t n, const double* pos, const double*
     for (size_t i = 0; i < n; i++) d->ids[i] = id ? id[i] : (uint64_t)i;
     d->capacity.assign(G, per + per / 4 + 4096);     // room for a quarter more than an even share
     d->bufs.assign(G, nbe_dist_buffers_t{});
+    double total_mass = 0.0;                         // fixes the quantum of the exact cell sums, alike on every GPU
+    for (size_t i = 0; i < n; i++) total_mass += mass[i];
     NBE_TRY(d->pool.run([&](int r) -> int {
         const size_t a = std::min(n, (size_t)r * per), z = std::min(n, ((size_t)r + 1) * per);
         NBE_TRY(nbe_dist_upload(m->subs[(size_t)r], r, (int)G, d->capacity[(size_t)r], z - a, pos + 3 * a, vel + 3 * a, mass + a, a));
+        NBE_TRY(nbe_dist_set_total_mass(m->subs[(size_t)r], total_mass));
         return nbe_dist_buffers(m->subs[(size_t)r], &d->bufs[(size_t)r]);
     }));
     NBE_TRY(dist_distribute(e));

@@ -795,7 +795,11 @@ static int launch_walk(nbe_engine* e, const void* src, uint64_t t0, uint64_t t1,
         // (mixed precision changes over at 1M bodies: its one-body kernel still tests every lane's sit-out index in every
         // visit, 17 vector instructions against 12, so two bodies per lane win earlier: two 512k-body galaxies 2.07 against
         // 2.13 ms)
-        const size_t least = __is_same(A, float) ? 3u * (1u << 20) : (1u << 20);
+        // (fp32 changes over at 2M bodies of a launch: level with one body per lane there, ahead from then on.  A rank of the
+        // key-range-distributed tree walks the tree of the whole run, longer walks per body than a scene of its own size has:
+        // 2.1M targets of a 16M-body tree take 3.78 ms with two bodies per lane against 4.27 ms with one, so it changes over
+        // at 1.5M.)
+        const size_t least = __is_same(A, float) ? (e->dist ? 3u * (1u << 19) : 2u * (1u << 20)) : (1u << 20);
         const bool pair = (forced == 2 || (forced != 1 && deciding >= least)) && !(count && !__is_same(A, float));
         if (pair) {
             dim3 pgrid(cdiv(nt, 2 * WALK_BLOCK));

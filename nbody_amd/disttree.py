@@ -24,8 +24,8 @@ except Exception:  # pragma: no cover - torch is part of the image
 MAX_FRAGMENTS = 2048
 MAX_BOXES = 8
 FRAGMENT = np.dtype([("key", "<u8"), ("level", "<i4"), ("start", "<i4"), ("nodes", "<i4"), ("reserved", "<i4"),
-                     ("sum", "<f8", (4,))])
-assert FRAGMENT.itemsize == 56
+                     ("sum", "<u8", (8,))])
+assert FRAGMENT.itemsize == 88
 
 
 class DistBuffers(C.Structure):
@@ -45,6 +45,7 @@ def _declare(lib):
     lib.nbe_dist_upload.argtypes = [vp, C.c_int, C.c_int, C.c_size_t, C.c_size_t, dp, dp, dp, C.c_uint64]
     lib.nbe_dist_sample_keys.argtypes = [vp, C.c_size_t, u64p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
     lib.nbe_dist_set_splitters.argtypes = [vp, u64p]
+    lib.nbe_dist_set_total_mass.argtypes = [vp, C.c_double]
     lib.nbe_dist_buffers.argtypes = [vp, C.POINTER(DistBuffers)]
     lib.nbe_dist_classify.argtypes = [vp, C.POINTER(C.c_uint32)]
     lib.nbe_dist_receive.argtypes = [vp, C.c_size_t]
@@ -61,7 +62,7 @@ def _declare(lib):
     _declared = True
 
 
-TOP_CELL = np.dtype([("dst", "<i4"), ("skip", "<i4"), ("level", "<i4"), ("reserved", "<i4"), ("sum", "<f8", (4,))])
+TOP_CELL = np.dtype([("dst", "<i4"), ("skip", "<i4"), ("level", "<i4"), ("reserved", "<i4"), ("sum", "<u8", (8,))])
 
 
 def layout(all_frags, sizes):
@@ -82,7 +83,7 @@ def layout(all_frags, sizes):
     return tops[:nt.value].copy(), dst[:n].copy(), total.value
 
 
-DIST_EXPORTS = ["nbe_dist_layout", "nbe_dist_energy", "nbe_dist_upload", "nbe_dist_sample_keys", "nbe_dist_set_splitters", "nbe_dist_buffers", "nbe_dist_classify",
+DIST_EXPORTS = ["nbe_dist_layout", "nbe_dist_energy", "nbe_dist_set_total_mass", "nbe_dist_upload", "nbe_dist_sample_keys", "nbe_dist_set_splitters", "nbe_dist_buffers", "nbe_dist_classify",
                 "nbe_dist_receive", "nbe_dist_build", "nbe_dist_export", "nbe_dist_assemble", "nbe_dist_advance",
                 "nbe_dist_download"]
 
@@ -122,6 +123,7 @@ class DistRank:
         self._check(self._lib.nbe_dist_upload(self._h, self.rank, self.world, int(capacity), mass.shape[0], _dp(pos), _dp(vel),
                                               _dp(mass), int(first_index)))
         self.capacity = int(capacity)
+        self.local_mass = float(mass.sum())
         self.engine.n = self.capacity
         b = DistBuffers()
         self._check(self._lib.nbe_dist_buffers(self._h, C.byref(b)))
@@ -148,6 +150,10 @@ class DistRank:
         self._check(self._lib.nbe_dist_sample_keys(self._h, max_samples, keys.ctypes.data_as(C.POINTER(C.c_uint64)),
                                                    C.byref(cnt), C.byref(live)))
         return keys[:cnt.value], live.value
+
+    def set_total_mass(self, total):
+        """The run's total mass (all ranks, the same value everywhere): the quantum of the exact cell sums follows from it."""
+        self._check(self._lib.nbe_dist_set_total_mass(self._h, float(total)))
 
     def set_splitters(self, split):
         split = np.ascontiguousarray(split, dtype=np.uint64)
@@ -361,6 +367,7 @@ class DistributedTree:
         self.rebalances = 0
         self._prepared = False
         self._want_rebalance = False
+        self._have_total = False
         self.lives = None
 
     def distribute(self, max_samples=4096):
@@ -368,6 +375,12 @@ class DistributedTree:
         got = [r.sample_keys(max_samples) for r in self.ranks]
         samples = self.comm.allgather([g[0] for g in got])
         lives = self.comm.allgather([np.array([g[1]], dtype=np.int64) for g in got])
+        if not self._have_total:
+            # every rank adds the ranks' masses in rank order: the same total, and with it the same quantum, everywhere
+            masses = self.comm.allgather([np.array([r.local_mass]) for r in self.ranks])
+            for k, r in enumerate(self.ranks):
+                r.set_total_mass(float(sum(float(a[0]) for a in masses[k])))
+            self._have_total = True
         for k, r in enumerate(self.ranks):
             split = choose_splitters(samples[k], [int(a[0]) for a in lives[k]], self.world)
             r.set_splitters(split)

@@ -121,12 +121,14 @@ class Engine:
 
     def __init__(self, mode="direct", precision="f32", theta=None, dt=None, eps=None, G=None,
                  bound_center=None, bound_width=None, device=0, collisions=False, ref_com=False,
-                 drop_tail=False, per_wave=False, devices=None, tree_sums=False, distributed=False):
+                 drop_tail=False, per_wave=False, devices=None, tree_sums=False, exact_sums=False, distributed=False):
         """devices: a list of HIP device ordinals; with more than one the engine itself drives all of them from this
         process (targets split into contiguous ranges, ranges copied between the GPUs every step); the same ordinal
         may appear more than once.
         tree_sums: fp32 node records take their cells' sums child by child in octant order (NBE_SUMS_TREE) instead of
-        from prefix sums: bits that do not depend on how the bodies are partitioned, as the distributed build needs."""
+        from prefix sums.
+        exact_sums: cells take their sums from 128-bit integer prefix sums (NBE_SUMS_EXACT): bits that do not depend on
+        how the bodies are partitioned, which is what the key-range-distributed build uses and equals bit for bit."""
         self._lib = load_library()
         cfg = Config()
         self._check(self._lib.nbe_default_config(C.byref(cfg)))
@@ -149,7 +151,7 @@ class Engine:
             ids = (C.c_int * len(devices))(*[int(d) for d in devices])
             cfg.num_devices = len(devices)
             cfg.device_ids = C.cast(ids, C.POINTER(C.c_int))
-        cfg.cell_sums = 1 if tree_sums else 0
+        cfg.cell_sums = 2 if exact_sums else (1 if tree_sums else 0)
         # several devices: every body on one GPU only, pruned subtrees exchanged (instead of all bodies on every GPU)
         cfg.distributed = 1 if distributed else 0
         cfg.collisions = int(bool(collisions))      # False = the reference's -nocollision run (main.go:24)

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layouts_match_header_sizes():
     assert C.sizeof(E.Config) == 2 * 4 + 4 * 8 + 3 * 8 + 8 + 4 * 4 + 4 + 4 + 8 + 8      # ... num_devices, cell_sums, device_ids, distributed + padding
     from nbody_amd import disttree
-    assert C.sizeof(disttree.DistBuffers) == 4 * 8 + 3 * 8 + 2 * 4 and disttree.FRAGMENT.itemsize == 8 + 4 * 4 + 4 * 8
+    assert C.sizeof(disttree.DistBuffers) == 4 * 8 + 3 * 8 + 2 * 4 and disttree.FRAGMENT.itemsize == 8 + 4 * 4 + 8 * 8
     assert C.sizeof(E.Stats) == 8 * 8 + 4 * 4
     assert C.sizeof(E.DeviceState) == 4 * 8 + 8 + 4 + 4 + 8
 

@@ -84,6 +84,20 @@ def test_spanning_cells_rebuilt_from_fragments_are_the_octrees_cells():
             kmax[i] = kmin[i] + size - 1
         order = np.sort(keys)
         split = [0] + [int(order[len(order) * k // world]) for k in range(1, world)] + [1 << 63]
+        # sums travel as 128-bit two's complement integers (low word first) in a quantum of the run: here 2^-40
+        def words(vals):
+            out = []
+            for v in vals:
+                q = int(round(float(v) * 2.0 ** 40)) % (1 << 128)
+                out += [q & ((1 << 64) - 1), q >> 64]
+            return out
+
+        def values(w):
+            out = []
+            for k in range(4):
+                q = int(w[2 * k]) | (int(w[2 * k + 1]) << 64)
+                out.append((q - (1 << 128) if q >> 127 else q) / 2.0 ** 40)
+            return np.array(out)
         frags, sizes, where = [], [], []
         for r in range(world):
             inside = [kmin[i] >= split[r] and kmax[i] < split[r + 1] for i in range(n)]
@@ -93,7 +107,7 @@ def test_spanning_cells_rebuilt_from_fragments_are_the_octrees_cells():
                     f["key"] = first_leaf_key[i]
                     f["level"] = 255 if keep["kind"][i] == 0 else depth[i]
                     f["start"], f["nodes"] = i, end[i] - i
-                    f["sum"][0] = [keep["mass"][i]] + [keep["mass"][i] * keep["com"][i][k] for k in range(3)]
+                    f["sum"][0] = words([keep["mass"][i]] + [keep["mass"][i] * keep["com"][i][k] for k in range(3)])
                     frags.append(f); sizes.append(end[i] - i); where.append(i)
         frags = np.concatenate(frags)
         assert all(int(a) < int(b) for a, b in zip(frags["key"][:-1], frags["key"][1:]))
@@ -106,5 +120,6 @@ def test_spanning_cells_rebuilt_from_fragments_are_the_octrees_cells():
         for t in tops:
             i = t["dst"]
             assert keep["kind"][i] == 1 and t["level"] == depth[i] and t["skip"] == end[i]
-            assert t["sum"][0] == pytest.approx(keep["mass"][i], rel=1e-13)
-            assert np.abs(t["sum"][1:] / t["sum"][0] - np.array(keep["com"][i])).max() <= 1e-9
+            got = values(t["sum"])
+            assert got[0] == pytest.approx(keep["mass"][i], rel=1e-13)
+            assert np.abs(got[1:] / got[0] - np.array(keep["com"][i])).max() <= 1e-9

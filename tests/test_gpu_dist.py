@@ -2,7 +2,7 @@
 pruned fragments exchanged.  Checked against ONE engine stepping all bodies (whose own parity with the CPU restatement
 is the business of tests/test_gpu_tree.py): every body must visit the nodes it visits in the one octree, in the same
 order, so fp32 and fp64 runs agree bit for bit when the one engine also sums its cells child by child
-(tree_sums=True); mixed precision flushes its partial sums by wavefront and agrees to rounding."""
+(exact_sums=True); mixed precision flushes its partial sums by wavefront and agrees to rounding."""
 import numpy as np
 import pytest
 
@@ -35,20 +35,21 @@ def run_distributed(b, world, nsteps, capacity=None, per_step=None, rebalance_at
 
 
 def run_one(b, nsteps, **kw):
-    with Engine(mode="tree", tree_sums=True, **kw) as e:
+    with Engine(mode="tree", exact_sums=True, **kw) as e:
         e.upload(b.pos, b.vel, b.mass)
         e.step(nsteps)
         p, v, m, ids = e.download()
     return ids, p, v, m
 
 
-def test_cells_summed_child_by_child_equal_the_prefix_sums_to_rounding(gpu):
-    """NBE_SUMS_TREE on fp32 node records: the same cells, masses and centres as the default build to fp32 rounding, and
-    the centres of the pointer octree of the CPU restatement."""
+@pytest.mark.parametrize("how", ["tree_sums", "exact_sums"])
+def test_cells_summed_child_by_child_equal_the_prefix_sums_to_rounding(gpu, how):
+    """NBE_SUMS_TREE and NBE_SUMS_EXACT on fp32 node records: the same cells, masses and centres as the default build to
+    fp32 rounding, and the centres of the pointer octree of the CPU restatement."""
     b = physics.plummer(30000, seed=3, a=2e3)
     tabs = []
-    for tree_sums in (False, True):
-        with Engine(mode="tree", precision="f32", theta=0.5, tree_sums=tree_sums) as e:
+    for kw in ({}, {how: True}):
+        with Engine(mode="tree", precision="f32", theta=0.5, **kw) as e:
             e.upload(b.pos, b.vel, b.mass)
             tabs.append(e.tree_nodes())
     a, t = tabs
@@ -225,7 +226,7 @@ def test_energy_of_a_distributed_run(gpu):
     finally:
         for r in ranks:
             r.close()
-    with Engine(mode="tree", precision="f32", theta=0.5, eps=1.0, tree_sums=True) as e:
+    with Engine(mode="tree", precision="f32", theta=0.5, eps=1.0, exact_sums=True) as e:
         e.upload(b.pos, b.vel, b.mass)
         e.step(2)
         ke1, pe1, mom1 = e.energy()
@@ -318,7 +319,7 @@ def test_distributed_tree_behind_one_engine_handle(gpu, precision, n, devices):
     want = run_one(b, 4, precision=precision, theta=0.6)
     assert np.array_equal(ids, want[0] + 1000)
     assert np.array_equal(p, want[1]) and np.array_equal(v, want[2]) and np.array_equal(m, want[3])
-    with Engine(mode="tree", precision=precision, theta=0.6, tree_sums=True) as one:
+    with Engine(mode="tree", precision=precision, theta=0.6, exact_sums=True) as one:
         one.upload(b.pos, b.vel, b.mass)
         one.step(2)
         ke1, pe1, mom1 = one.energy()              # (the exact pair sum at these sizes; the distributed run sums over accepted nodes)
@@ -345,7 +346,7 @@ def test_frame_stream_of_a_distributed_engine(gpu, precision, devices):
         e.frame_stream_end()                      # ending twice is harmless
     assert sorted(got) == [5, 6, 7, 8]            # steps 0, 2, 4, 6
     want = {}
-    with Engine(mode="tree", precision=precision, theta=0.6, tree_sums=True) as one:
+    with Engine(mode="tree", precision=precision, theta=0.6, exact_sums=True) as one:
         one.upload(b.pos, b.vel, b.mass, ids=ids)
         one.frame_stream_begin(lambda f, xyzm, i, r: want.__setitem__(f, (xyzm.copy(), i.copy())), every=every, slots=2, first_frame=5)
         one.step(nsteps)

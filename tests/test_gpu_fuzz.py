@@ -122,7 +122,7 @@ def test_random_scenes_on_the_distributed_tree_equal_one_engine(gpu, block):
         theta = float(rng.choice([0.3, 0.6, 1.0]))
         tag = f"seed {s}: {kind} n={n} {precision} shards={shards} steps={nsteps} theta={theta}"
         out = []
-        for kw in (dict(tree_sums=True), dict(devices=[0] * shards, distributed=True)):
+        for kw in (dict(exact_sums=True), dict(devices=[0] * shards, distributed=True)):
             with Engine(mode="tree", precision=precision, theta=theta, dt=200.0, **kw) as e:
                 e.upload(pos, vel, mass)
                 e.step(nsteps)

@@ -342,7 +342,7 @@ def test_upload_right_after_a_step_of_a_several_shard_engine(gpu, distributed):
     other bodies, step, with no synchronisation in between: the second scene must come out as from a fresh engine."""
     b1 = physics.plummer(30001, seed=21, a=2e3)
     b2 = physics.plummer(20001, seed=22, a=2e3)
-    kw = dict(tree_sums=True) if distributed else {}
+    kw = dict(exact_sums=True) if distributed else {}
     with Engine(mode="tree", precision="f32", theta=0.6, **kw) as one:
         one.upload(b2.pos, b2.vel, b2.mass)
         one.step(3)
