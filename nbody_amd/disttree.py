@@ -356,10 +356,14 @@ def choose_splitters(samples, lives, world):
 class DistributedTree:
     """Steps the ranks that live in this process (all of them with LocalComm, one with TorchComm)."""
 
-    def __init__(self, ranks, comm, rebalance_at=1.10):
+    def __init__(self, ranks, comm, rebalance_at=1.10, freeze_gc=True):
         """rebalance_at: new splitters are chosen before a step when the fullest rank holds this many times the mean
         number of bodies (the bodies' distribution over key space drifts as the system evolves), or when a rank has filled
-        nine tenths of its slots; None = never."""
+        nine tenths of its slots; None = never.
+        freeze_gc: a step makes a few hundred short-lived lists and arrays, which sets off Python's cyclic collector
+        every few steps; a full collection walks every object of the process (35 ms with torch loaded, measured: one step
+        in eight took 75 ms instead of 40), so the objects that exist when the run starts are moved out of its sight once
+        (gc.freeze), after which a collection only looks at what the steps themselves made."""
         self.ranks, self.comm = list(ranks), comm
         self.world = comm.world
         self.timings = None
@@ -368,6 +372,7 @@ class DistributedTree:
         self._prepared = False
         self._want_rebalance = False
         self._have_total = False
+        self._freeze_gc = freeze_gc
         self.lives = None
 
     def distribute(self, max_samples=4096):
@@ -385,6 +390,11 @@ class DistributedTree:
             split = choose_splitters(samples[k], [int(a[0]) for a in lives[k]], self.world)
             r.set_splitters(split)
         self.split = split
+        if self._freeze_gc:
+            import gc
+            gc.collect()
+            gc.freeze()
+            self._freeze_gc = False
         return split
 
     def step(self, nsteps=1):
