@@ -98,10 +98,27 @@ def cpu_baseline_tree(n, theta):
             "sample": f"one force pass on {n} bodies, theta={theta}, serial build + 4 walk threads"}
 
 
+def one_gpu_reference(key, field="steps_per_s"):
+    """A figure of the newest committed one-GPU run of this bench (profiles/rNN_bench_default.json): what a run on
+    several GPUs is compared with in its own line."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_default.json")), reverse=True):
+        try:
+            with open(path) as f:
+                d = json.load(f)
+            v = d.get("extra", {}).get(key, {}).get(field) if key else d.get(field)
+            if v is not None:
+                return {"value": v, "from": os.path.basename(path)}
+        except Exception:
+            continue
+    return None
+
+
 def eight_ranks_on_one_gpu(b, one_gpu_ms, **engine_kw):
-    """A scene on the key-range-distributed tree with eight ranks side by side on the current GPU, phases drained one by
-    one: a rank's share of the sums is what one GPU of an eight-GPU run does per step (the exchanges are device copies
-    here).  Medians over five steps, so that one stalled phase does not colour the table."""
+    """A scene on the key-range-distributed tree with eight ranks side by side on the current GPU.  Two figures per
+    rank: the timed step (ten steps end to end, nothing drained in between, divided by the eight ranks that take turns on
+    the GPU: kernels, launches, read-backs and host work of a rank, with device copies where a real run has its
+    exchanges), and the phase table (phases drained one by one, medians over five steps)."""
     import torch
     from nbody_amd.disttree import DistRank, DistributedTree, LocalComm
     nr = 8
@@ -117,10 +134,15 @@ def eight_ranks_on_one_gpu(b, one_gpu_ms, **engine_kw):
         tree = DistributedTree(ranks, LocalComm(nr))
         tree.distribute()
         tree.step(2)                    # (the first step moves every body to its owner)
+        timed_s = timed_steps(lambda: tree.step(1), torch.cuda.synchronize, lambda: None, 1, 10)
+        timed_ms = 1e3 * timed_s / 10 / nr
         runs = [tree.step_profiled() for _ in range(5)]
         acc = {k: float(np.median([t[k] for t in runs])) for k in runs[0]}
         per_rank = {k: v / nr for k, v in acc.items()}
-        return {"phase_ms_sum_over_ranks": acc, "phase_ms_per_rank": per_rank, "ms_per_step_per_rank": sum(per_rank.values()),
+        return {"timed_ms_per_step_per_rank": timed_ms, "ratio_one_gpu_step_to_timed_rank_step": one_gpu_ms / timed_ms,
+                "timed": "10 steps of all eight ranks end to end without drains, divided by 8",
+                "walk_kernel": "two bodies per lane (a rank changes over at 1.5M targets in fp32, 1M in mixed precision)",
+                "phase_ms_sum_over_ranks": acc, "phase_ms_per_rank": per_rank, "ms_per_step_per_rank": sum(per_rank.values()),
                 "one_gpu_ms_per_step": one_gpu_ms, "ratio_one_gpu_step_to_rank_step": one_gpu_ms / sum(per_rank.values()),
                 "imported_nodes_per_rank": tree.last_import_nodes, "migrated_bodies_per_rank": tree.last_migrated,
                 "bodies_per_rank": [int(r.engine.stats().n_alive) for r in ranks], "rebalances": tree.rebalances}
@@ -211,6 +233,11 @@ def main():
                 "profiled_clock_ghz": traffic_from_profiles(workload, "clock_ghz")}
     extra = {}
     if world > 1 or force_dist:
+        extra["world"] = {"WORLD_SIZE": world, "rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(),
+                          "devices_visible": torch.cuda.device_count(), "local_rank": local}
+        ref = one_gpu_reference(None, "steps_per_s")
+        if ref:
+            extra["world"]["headline_steps_per_s_over_one_gpu"] = {"ratio": (args.steps / sec) / ref["value"], "one_gpu": ref}
         # the headline step phase by phase (exchanges blocking, maximum over the ranks)
         prof = ShardedStepper(EngineShard(eng, device_index=local), always_gather=force_dist)
         prof.step_profiled()
@@ -269,6 +296,10 @@ def main():
                                                  "interactions_per_step": i3, "interactions_per_s": i3 * 5 / s3, "force_kernel_ms": kms3,
                                                  "force_kernel": "walk_pair_kernel<float> (two bodies per lane)" if world == 1 else "by the shard's size",
                                                  "force_kernel_frac_of_fp32_valu_peak": (i3 / world) * FLOP_PER_INTERACTION / (kms3 * 1e-3) / 1e12 / FP32_VALU_PEAK_TFLOPS}
+        if world > 1 or force_dist:
+            ref = one_gpu_reference("bh_theta0.5_fp32_plummer_16M")
+            if ref:
+                extra["bh_theta0.5_fp32_plummer_16M"]["steps_per_s_over_one_gpu"] = {"ratio": (5 / s3) / ref["value"], "one_gpu": ref}
         if st3 is not None:
             extra["bh_theta0.5_fp32_plummer_16M"].update({
                 "ms_sort": st3.ms_sort, "ms_build": st3.ms_build, "ms_force": st3.ms_force,
@@ -328,6 +359,9 @@ def main():
                                           "momentum_drift_rel": float(np.linalg.norm(p1 - p0)) / pscale}},
             "stated_bound": "|dE/E0| <= 2e-3 and |dP|/sum m|v| <= 1e-5 after 100 steps (the bounds tests/test_gpu_config5.py asserts on one GPU)",
             "parallelism": f"targets sharded over {world} GPU(s), replicated build, all-gather of pos+vel per step"}
+        ref = one_gpu_reference("galaxy_pair_2x8M_bh_mixed_eps1")
+        if ref:
+            extra["galaxy_pair_2x8M_bh_mixed_eps1_sharded"]["steps_per_s_over_one_gpu"] = {"ratio": (98 / sec5) / ref["value"], "one_gpu": ref}
         e5.close()
 
     if not args.no_extra and world == 1:
@@ -521,8 +555,10 @@ def main():
                 t = torch.tensor([live, -live], device="cuda", dtype=torch.float64)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 live = [float(t[0].item()), -float(t[1].item())]
+            ref = one_gpu_reference("bh_theta0.5_fp32_plummer_16M" if "plummer" in key else "galaxy_pair_2x8M_bh_mixed_eps1")
             extra[key] = {
                 "steps_per_s": 5 / sec, "ms_per_step": 1e3 * sec / 5, "phase_ms_max_over_ranks": acc,
+                "steps_per_s_over_one_gpu": {"ratio": (5 / sec) / ref["value"], "one_gpu": ref} if ref else None,
                 "bodies_per_rank_max_min": live, "imported_nodes_this_rank": tree.last_import_nodes[0],
                 "migrated_bodies_this_rank": tree.last_migrated[0]}
             for rr in ranks:
@@ -541,7 +577,7 @@ def main():
                 extra.setdefault("bh_theta0.5_fp32_plummer_16M_distributed_tree", {"error": "did not finish in time; the rest of the line is complete"})
                 extra.setdefault("galaxy_pair_2x8M_bh_mixed_eps1_distributed_tree", {"error": "did not finish in time; the rest of the line is complete"})
                 emit()
-                os._exit(0)
+                os._exit(3)                   # the line is out; the exit code says that a collective did not come back
         threading.Thread(target=watchdog, daemon=True).start()
         try:
             distributed_tree_extra()
@@ -563,10 +599,11 @@ def main():
     if world > 1 or force_dist:
         # a rank that failed above while the others were inside a collective would wait here for ever
         import threading
-        threading.Timer(120.0, lambda: os._exit(0)).start()
+        failed = any(isinstance(v, dict) and "error" in v for v in extra.values())
+        threading.Timer(120.0, lambda: os._exit(3)).start()      # (the line is out already; a barrier nobody joins must not pass for success)
         dist.barrier()
         dist.destroy_process_group()
-        os._exit(0)
+        os._exit(3 if failed else 0)
 
 
 if __name__ == "__main__":

@@ -272,6 +272,20 @@ class TorchComm:
     def allgather(self, per_rank):
         return [[got[0] for got in self.allgather_many([[per_rank[0]]])[0]]]
 
+    def _buffers(self, cap):
+        """Staging for the small gathers, kept from step to step: a pinned host buffer and a device buffer on either side
+        of the collective (pageable memory would be pinned and unpinned by the runtime in every copy, and fresh tensors
+        go through the allocator)."""
+        if getattr(self, "_cap", 0) != cap:
+            on_gpu = self.device.type == "cuda"
+            self._hsend = torch.zeros(cap, dtype=torch.uint8, pin_memory=on_gpu)
+            self._hrecv = torch.zeros(self.world * cap, dtype=torch.uint8, pin_memory=on_gpu)
+            self._dsend = torch.zeros(cap, dtype=torch.uint8, device=self.device) if on_gpu else self._hsend
+            self._drecv = torch.zeros(self.world * cap, dtype=torch.uint8, device=self.device) if on_gpu else self._hrecv
+            self._hsend_np, self._hrecv_np = self._hsend.numpy(), self._hrecv.numpy()
+            self._cap = cap
+        return self._hsend_np, self._hrecv_np
+
     def allgather_many(self, per_rank):
         """One collective for several small arrays: every rank sends [total bytes | byte length of each array | the
         arrays], padded to a capacity that all ranks hold alike; a rank that sees a longer message from anybody doubles
@@ -281,19 +295,23 @@ class TorchComm:
         head = np.array([0] + [b.size for b in blobs], dtype=np.int64)
         head[0] = 8 * head.size + int(head[1:].sum())
         msg = np.concatenate([head.view(np.uint8)] + blobs)
-        cap = getattr(self, "_cap", 1 << 16)
+        cap = getattr(self, "_cap", 0) or 1 << 16
         while True:
-            send = torch.zeros(cap, dtype=torch.uint8)
+            hsend, hrecv = self._buffers(cap)
             k = min(cap, msg.size)
-            send[:k] = torch.from_numpy(msg[:k].copy())
-            out = torch.zeros(self.world * cap, dtype=torch.uint8, device=self.device)
-            dist.all_gather_into_tensor(out, send.to(self.device), group=self.group)
-            out = out.cpu().numpy().reshape(self.world, cap)
+            hsend[:k] = msg[:k]
+            if self.device.type == "cuda":
+                self._dsend.copy_(self._hsend, non_blocking=True)
+                dist.all_gather_into_tensor(self._drecv, self._dsend, group=self.group)
+                self._hrecv.copy_(self._drecv, non_blocking=True)
+                torch.cuda.current_stream().synchronize()
+            else:
+                dist.all_gather_into_tensor(self._hrecv, self._hsend, group=self.group)
+            out = hrecv.reshape(self.world, cap)
             need = int(max(out[r, :8].view(np.int64)[0] for r in range(self.world)))
             if need <= cap:
                 break
             cap = 2 * need
-        self._cap = cap
         res = []
         for r in range(self.world):
             lens = out[r, 8:8 * head.size].view(np.int64)
@@ -310,10 +328,9 @@ class TorchComm:
         me = ranks[0]
         sc = [int(c) for c in send_counts[0]]
         if recv_counts is None:
-            t = torch.tensor(sc, dtype=torch.int64, device=self.device)
-            rc = torch.zeros_like(t)
-            dist.all_to_all_single(rc, t, group=self.group)
-            rc = rc.cpu().tolist()
+            # everybody's counts through the staged gather above: row r, column of this rank
+            rows = self.allgather_many([[np.asarray(sc, dtype=np.int64)]])[0]
+            rc = [int(rows[r][0][self.rank]) for r in range(self.world)]
         else:
             rc = [int(c) for c in recv_counts[0]]
         src, dst = me.bytes_view(which_send), me.bytes_view(which_recv)
