@@ -120,6 +120,7 @@ extern "C" int nbe_create(const nbe_config* cfg, nbe_engine** out)
         const long v = strtol(env, nullptr, 10);
         if (v == 1 || v == 2) e->walk_bodies_per_lane = (int)v;
     }
+    if (const char* env = getenv("NBODY_WALK_PRIVATE")) e->walk_private = env[0] == '1';     // measurement knob, see walk_private_kernel
     int rc = use_device(e);
     if (rc == NBE_OK && hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking) != hipSuccess) {
         nbe_set_error("hipStreamCreate failed");
@@ -626,6 +627,7 @@ static int fetch_interactions(nbe_engine* e)
         NBE_HIP(hipMemcpyAsync(v, e->tw.d_interactions, sizeof(v), hipMemcpyDeviceToHost, e->stream));
         NBE_HIP(hipStreamSynchronize(e->stream));
         e->stats.interactions = v[0];
+        if (e->walk_private && e->cfg.precision == NBE_PREC_F32) fprintf(stderr, "one-body-one-cursor walk: %llu node visits, %llu force evaluations\n", v[1], v[0]);
 #ifdef WALK_VISIT_STATS
         fprintf(stderr, "walk visits: sum %llu max %llu sumsq %llu hist(<3000,<4000,<6000,>=6000) %llu %llu %llu %llu\n", v[1], v[2],
                 v[3], v[4], v[5], v[6], v[7]);

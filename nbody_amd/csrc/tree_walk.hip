@@ -739,6 +739,52 @@ __global__ __launch_bounds__(WALK_BLOCK) void walk_pair_kernel(
 #define WALK_LAUNCH(...)                                                                                     \
     hipLaunchKernelGGL((soft ? walk_kernel<R, A, NodeT, __VA_ARGS__, true> : walk_kernel<R, A, NodeT, __VA_ARGS__, false>),
 
+// ---- yardstick: every body walks alone ----------------------------------------------------------------------------------
+// The classic traversal: one lane, one body, one cursor per lane, node records through vector loads at up to 64
+// addresses per instruction.  Every lane is busy in every step (no lane waits for another's cell), which is what a
+// walk that regroups bodies by the subtrees they open would offer its lanes, so its cost per step prices that idea;
+// it is also what the shared cursor is measured against.  Same arithmetic and order as walk_kernel: the same bits.
+// fp32, accelerations only; reached through NBODY_WALK_PRIVATE=1 (nbe_accel, nbe_time_force_kernel), never by a step.
+template <bool COUNT>
+__global__ __launch_bounds__(WALK_BLOCK) void walk_private_kernel(const NodeF* __restrict__ nodes, const int* __restrict__ counters,
+                                                                  const float4* __restrict__ posm, int t0, int t1, float floor2, float G,
+                                                                  float4* __restrict__ acc_out, unsigned long long* __restrict__ interactions)
+{
+    const int na = counters[0];
+    const int total = counters[1];
+    const int tend = t1 < na ? t1 : na;
+    const unsigned nwg = gridDim.x, q8 = nwg / 8, r8 = nwg % 8, xcd = blockIdx.x % 8;
+    const unsigned wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + blockIdx.x / 8;
+    const int i = t0 + (int)wg * WALK_BLOCK + threadIdx.x;
+    if (i >= tend) return;
+    const float4 p = posm[i];
+    float fx = 0, fy = 0, fz = 0, phi = 0;
+    unsigned count = 0, steps = 0;
+    const float4* rec = reinterpret_cast<const float4*>(nodes);
+    int cur = 0;
+    while (cur < total) {
+        const float4 a = rec[2 * (size_t)cur];                 // x, y, z, mass
+        const float4 b = rec[2 * (size_t)cur + 1];             // (edge / theta)^2 (+ eps^2), skip
+        const float dx = a.x - p.x, dy = a.y - p.y, dz = a.z - p.z;
+        const float r2 = fmaf(dx, dx, fmaf(dy, dy, fmaf(dz, dz, floor2)));
+        const bool open = r2 < b.x;
+        if (!open) {
+            const float rinv = rsq_dev(r2);
+            const float rinv2 = rinv * rinv;
+            const float w = rinv2 * (rinv * a.w);
+            fx = fmaf(dx, w, fx); fy = fmaf(dy, w, fy); fz = fmaf(dz, w, fz);
+            if (COUNT && (dx != 0.0f || dy != 0.0f || dz != 0.0f)) { count++; phi += rinv * a.w; }
+        }
+        cur = open ? cur + 1 : __float_as_int(b.y);
+        if (COUNT) steps++;
+    }
+    acc_out[i] = make_float4(G * fx, G * fy, G * fz, phi);
+    if (COUNT && interactions) {
+        atomicAdd(interactions, (unsigned long long)count);
+        atomicAdd(interactions + 1, (unsigned long long)steps);       // node visits of all lanes
+    }
+}
+
 template <typename R, typename A, typename NodeT>
 static int launch_walk(nbe_engine* e, const void* src, uint64_t t0, uint64_t t1, bool fused, bool count, int src_buf, int dst_buf)
 {
@@ -780,6 +826,21 @@ static int launch_walk(nbe_engine* e, const void* src, uint64_t t0, uint64_t t1,
 #undef GROUP_LAUNCH
         NBE_HIP(hipGetLastError());
         return NBE_OK;
+    }
+    if constexpr (__is_same(R, float) && __is_same(A, float)) {
+        if (e->walk_private && !fused && !(e->cfg.reference_quirks & NBE_QUIRK_DROP_TAIL)) {
+            dim3 grid(cdiv(nt, WALK_BLOCK));
+            if (count) {
+                NBE_HIP(hipMemsetAsync(e->tw.d_interactions, 0, 8 * sizeof(unsigned long long), e->stream));
+                hipLaunchKernelGGL((walk_private_kernel<true>), grid, dim3(WALK_BLOCK), 0, e->stream, (const NodeF*)e->tw.nodes, e->tw.counters,
+                                   (const float4*)src, (int)t0, (int)t1, floor2, G, (float4*)e->acc, e->tw.d_interactions);
+            } else {
+                hipLaunchKernelGGL((walk_private_kernel<false>), grid, dim3(WALK_BLOCK), 0, e->stream, (const NodeF*)e->tw.nodes, e->tw.counters,
+                                   (const float4*)src, (int)t0, (int)t1, floor2, G, (float4*)e->acc, e->tw.d_interactions);
+            }
+            NBE_HIP(hipGetLastError());
+            return NBE_OK;
+        }
     }
     if constexpr (__is_same(R, float)) {
         // fp32 visits: two bodies per lane where there are enough bodies to fill the GPU several times over with 128-body waves

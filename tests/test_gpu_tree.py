@@ -387,6 +387,26 @@ def test_walk_with_two_bodies_per_lane_where_it_is_chosen_by_itself(gpu, monkeyp
         assert np.array_equal(a, c)
 
 
+@pytest.mark.parametrize("n", [1, 2, 65, 1000, 20000, 300001])
+def test_every_lane_walking_alone_gives_the_bits_of_the_shared_cursor(gpu, monkeypatch, n):
+    """NBODY_WALK_PRIVATE=1 sends the fp32 force pass through the classic traversal (one cursor per lane, vector loads),
+    kept as a yardstick: the same interactions in the same order, so the same bits and the same count as walk_kernel."""
+    b = physics.plummer(n, seed=n % 11, a=2e3)
+    pos = b.pos.copy()
+    if n > 10:
+        pos[3] = pos[7]
+        pos[5] = [4e4, 0, 0]
+    monkeypatch.setenv("NBODY_WALK_BODIES_PER_LANE", "1")
+    out = []
+    for knob in ("0", "1"):
+        monkeypatch.setenv("NBODY_WALK_PRIVATE", knob)
+        with Engine(mode="tree", precision="f32", theta=0.6, eps=0.5) as e:
+            e.upload(pos, b.vel, b.mass)
+            acc, alive = e.accel()
+            out.append((acc, alive, e.stats().interactions))
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1]) and out[0][2] == out[1][2]
+
+
 @pytest.mark.parametrize("n", [2, 65, 129, 1000, 8193, 50001, 300000])
 def test_mixed_walk_with_two_bodies_per_lane_agrees_with_one_body_per_lane(gpu, monkeypatch, n):
     """Mixed precision has the same two kernels.  Its fp32 partial sums join the fp64 totals every 64 visits of the
