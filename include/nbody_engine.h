@@ -70,7 +70,7 @@ typedef struct {
  * from the first GPU; nbe_set_radius reaches every GPU).  Collisions work in tree mode (the GPUs share out the force pass and
  * each runs the search, the merges and the update of all bodies), not in the direct sum; nbe_step_timed, nbe_set_stream,
  * nbe_device_state and the nbe_shard_* calls are refused with NBE_E_UNSUPPORTED.  The same ordinal may be listed more than once (several shards on one GPU).
- * With cfg.distributed = 1 (tree mode, collisions off, per-body criterion, no reference_quirks) the GPUs do not replicate the
+ * With cfg.distributed = 1 (tree mode, per-body criterion, no reference_quirks; collisions allowed) the GPUs do not replicate the
  * bodies: the engine runs the key-range-distributed tree described at nbe_dist_upload below on its GPUs, one host thread per
  * GPU, with peer copies for the exchanges.  nbe_upload, nbe_step, nbe_download, nbe_stats, nbe_energy (tree potential),
  * nbe_sync and the frame stream work (no GPU holds all bodies: every GPU snapshots its own before the step and sends
@@ -243,8 +243,8 @@ int nbe_device_state(nbe_engine *e, nbe_device_state_t *out);
  *     upload index on one engine and by their run-wide index here, in runs of up to 64 such bodies, so they too are
  *     summed in one order everywhere; a longer run keeps the order in which its bodies reached the rank, and results
  *     then agree to rounding instead of bit for bit.)
- * Tree mode, collisions off, NBE_WALK_PER_BODY, no reference_quirks.  nbe_step and the nbe_shard_* calls are refused on
- * such an engine. */
+ * Tree mode, NBE_WALK_PER_BODY, no reference_quirks; collisions as described at nbe_dist_set_radius.  nbe_step and the
+ * nbe_shard_* calls are refused on such an engine. */
 typedef struct {
     uint64_t key;           /* Morton key of the fragment's first body */
     int32_t level;          /* depth of the fragment's root cell; 255: the fragment is one body */
@@ -256,7 +256,8 @@ typedef struct {
 } nbe_fragment_t;
 
 typedef struct {
-    void *outbox, *inbox;   /* migration records, `slots` of them each; a record is 2 * elem_bytes (position+mass, velocity+index) */
+    void *outbox, *inbox;   /* migration records, `slots` of them each; a record is record_bytes long (position+mass,
+                               velocity+index, and with collisions on the radius) */
     void *export_nodes;     /* what nbe_dist_export wrote: node records for the other ranks, destination after destination */
     void *import_nodes;     /* where the caller puts the records exported to this rank, source rank after source rank */
     uint64_t slots, export_cap, import_cap;   /* capacities in records / nodes */
@@ -277,6 +278,16 @@ int nbe_dist_sample_keys(nbe_engine *e, size_t max_samples, uint64_t *keys_out, 
 /* The total mass of the run's bodies (all ranks), the same value on every rank: it fixes the quantum of the exact cell sums
  * (NBE_SUMS_EXACT).  Needed once, before the first nbe_dist_build; an upper bound will do. */
 int nbe_dist_set_total_mass(nbe_engine *e, double total_mass);
+/* Collisions on (cfg.collisions = 1; tree.go:245-281, main.go:151-167, physics.go:153-162): radii of the rank's uploaded
+ * bodies in upload order (NULL keeps the reference's defaultRadius 2, physics.go:20) and the largest radius any body of the
+ * run may reach, the same value on every rank (default 32 m).  A collision search stays inside the cells around its body
+ * that are at most four radii wide; nbe_dist_set_splitters moves every splitter down to the border of a cell at least four
+ * caps wide, so such cells, the pairs a search can queue and the pairs that share a body all lie on one rank, and every
+ * rank searches, merges (its own pairs in the reference's queue order) and updates for itself after the force pass.  Queue
+ * lengths, merges and survivors equal those of one engine.  A body whose radius grows beyond the cap, or more than 16,384
+ * bodies of one rank queueing pairs in one step, makes nbe_dist_advance fail with NBE_E_UNSUPPORTED.  Right after
+ * nbe_dist_upload, before nbe_dist_set_splitters. */
+int nbe_dist_set_radius(nbe_engine *e, const double *radius, double radius_cap);
 /* split[0] = 0 <= split[1] <= ... <= split[world] = 2^63: rank r owns keys in [split[r], split[r+1]). */
 int nbe_dist_set_splitters(nbe_engine *e, const uint64_t *split);
 int nbe_dist_buffers(nbe_engine *e, nbe_dist_buffers_t *out);

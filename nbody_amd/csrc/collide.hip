@@ -21,6 +21,8 @@
 
 struct Cell { double cx, cy, cz, w; };
 
+#define RANK_QUEUE_CAP 16384     // bodies of one rank of the distributed tree that may queue pairs in one step
+
 // Centre and edge of the depth-`level` cell that contains `key`: exact for a power-of-two bound, and equal to
 // what octantBound (tree.go:101-110) reaches by repeated quarter-edge translations.
 __device__ __forceinline__ Cell cell_of(uint64_t key, int level, double lox, double loy, double loz, double W)
@@ -102,6 +104,16 @@ __device__ __forceinline__ bool confined(const Cell& pc, unsigned mask, double p
     return fabs(px - ccx) <= cw && fabs(py - ccy) <= cw && fabs(pz - ccz) <= cw;
 }
 
+// On a rank of the key-range-distributed tree the upload (run-wide) indices of the bodies do not number a local array,
+// so the counts and offsets are kept per sorted body there, and the bodies that queue anything are listed (unordered,
+// through one atomic each) for collide_rank_kernel to put into the reference's queue order.  list == nullptr: one engine.
+struct RankQueue {
+    uint4* list;            // (run-wide index, sorted index, pairs queued, 0) of every body that queues pairs
+    uint32_t* meta;         // [0] entries of the list, [1] pairs in all, [2] bit 0: a radius above rcap, bit 1: list overflow
+    int cap;
+    double rcap;            // searches of bodies with larger radii could reach beyond the rank's own cells
+};
+
 // tree.go:245-281 for sorted body t.  FILL = false counts the pairs the body queues (into count[upload index]);
 // FILL = true writes them at offset[upload index] in the order the recursion meets them (children 0..7).
 //
@@ -119,12 +131,14 @@ __global__ __launch_bounds__(256) void collide_search_kernel(const CNode* __rest
                                                              const uint32_t* __restrict__ cellcnt,
                                                              double lox, double loy, double loz, double W,
                                                              uint32_t* __restrict__ count, const uint32_t* __restrict__ offset,
-                                                             int2* __restrict__ pairs)
+                                                             int2* __restrict__ pairs, RankQueue rq)
 {
     const int na = counters[0];
     const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= na || na < 2) return;
+    if (t >= na) return;
     const double R = radius[t];
+    if (!FILL && rq.list && R > rq.rcap) atomicOr(&rq.meta[2], 1u);
+    if (na < 2) return;
     const double reach = 4.000001 * R;                 // cells at least this wide confine the search for certain
     {
         // the deepest cell above the body is the one it shares with its nearer neighbour in key order
@@ -149,7 +163,8 @@ __global__ __launch_bounds__(256) void collide_search_kernel(const CNode* __rest
         c = nd.parent;
     }
     if (top < 0) return;
-    const uint32_t base = FILL ? offset[orig[t]] : 0u;
+    const uint32_t slot = rq.list ? (uint32_t)t : orig[t];       // where this body's count and offset live
+    const uint32_t base = FILL ? offset[slot] : 0u;
     uint32_t found = 0;
     const int end = cn[top].skip;
     int cur = top + 1;
@@ -180,7 +195,50 @@ __global__ __launch_bounds__(256) void collide_search_kernel(const CNode* __rest
             cur++;
         }
     }
-    if (!FILL) count[orig[t]] = found;
+    if (!FILL) {
+        count[slot] = found;
+        if (rq.list && found) {
+            const uint32_t k = atomicAdd(&rq.meta[0], 1u);
+            if (k < (uint32_t)rq.cap) rq.list[k] = make_uint4(orig[t], (uint32_t)t, found, 0u);
+            else atomicOr(&rq.meta[2], 2u);
+        }
+    }
+}
+
+// The reference queues the pairs of the searching bodies in slice order (main.go:153-159), i.e. by upload index; pairs
+// that share a body always sit on one rank, so a rank that works its own pairs off in that order does what the one
+// queue does.  Entry i goes to the place given by the number of entries with a smaller run-wide index (they are few).
+__global__ __launch_bounds__(256) void collide_rank_kernel(const uint4* __restrict__ list, const uint32_t* __restrict__ meta, int cap,
+                                                           uint4* __restrict__ sorted)
+{
+    const int m = (int)min(meta[0], (uint32_t)cap);
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= m) return;
+    const uint4 me = list[i];
+    int before = 0;
+    for (int j = 0; j < m; j++) before += list[j].x < me.x ? 1 : 0;
+    sorted[before] = me;
+}
+
+// One wave: running sum of the entries' pair counts in queue order; every listed body learns where its pairs go.
+__global__ __launch_bounds__(64) void collide_offsets_kernel(const uint4* __restrict__ sorted, uint32_t* __restrict__ meta, int cap,
+                                                             uint32_t* __restrict__ offset)
+{
+    const int m = (int)min(meta[0], (uint32_t)cap);
+    const int lane = threadIdx.x;
+    uint32_t carry = 0;
+    for (int base = 0; base < m; base += 64) {
+        const int k = base + lane;
+        const uint4 en = k < m ? sorted[k] : make_uint4(0, 0, 0, 0);
+        uint32_t inc = en.z;
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t up = __shfl_up(inc, d, 64);
+            if (lane >= d) inc += up;
+        }
+        if (k < m) offset[en.y] = carry + inc - en.z;
+        carry += __shfl(inc, 63, 64);
+    }
+    if (lane == 0) meta[1] = carry;
 }
 
 // combine (physics.go:153-162) for one queued pair, unless an earlier merge removed one of the two (main.go:161-163).
@@ -296,7 +354,8 @@ static int free_ptr(void** p)
 int collide_workspace_free(nbe_engine* e)
 {
     CollWork& w = e->cw;
-    void** ptrs[] = {(void**)&w.cnodes, (void**)&w.count, (void**)&w.offset, (void**)&w.pairs, (void**)&w.dead};
+    void** ptrs[] = {(void**)&w.cnodes, (void**)&w.count, (void**)&w.offset, (void**)&w.pairs, (void**)&w.dead, (void**)&w.rank_list,
+                     (void**)&w.rank_meta};
     for (void** p : ptrs) NBE_TRY(free_ptr(p));
     if (w.total_host) { NBE_HIP(hipHostFree(w.total_host)); w.total_host = nullptr; }
     w.cap = 0; w.pairs_cap = 0; w.begun = false;
@@ -307,8 +366,17 @@ int collide_workspace_reserve(nbe_engine* e)
 {
     CollWork& w = e->cw;
     const size_t cap = e->n > 0 ? e->n : 1;
+    if (e->dist && e->cfg.collisions && !w.rank_list) {
+        NBE_HIP(hipMalloc((void**)&w.rank_list, 2 * (size_t)RANK_QUEUE_CAP * sizeof(uint4)));
+        NBE_HIP(hipMalloc((void**)&w.rank_meta, 4 * sizeof(uint32_t)));
+    }
     if (w.cap >= cap) return NBE_OK;
-    NBE_TRY(collide_workspace_free(e));
+    {   // (the list of a distributed rank does not depend on the body count: it survives the reallocation below)
+        uint4* keep_list = w.rank_list; uint32_t* keep_meta = w.rank_meta;
+        w.rank_list = nullptr; w.rank_meta = nullptr;
+        NBE_TRY(collide_workspace_free(e));
+        w.rank_list = keep_list; w.rank_meta = keep_meta;
+    }
     NBE_HIP(hipMalloc((void**)&w.cnodes, (2 * cap + 2) * sizeof(CNode)));
     NBE_HIP(hipMalloc((void**)&w.count, (cap + 1) * 4));
     NBE_HIP(hipMalloc((void**)&w.offset, (cap + 1) * 4));
@@ -316,7 +384,7 @@ int collide_workspace_reserve(nbe_engine* e)
     NBE_HIP(hipMemsetAsync(w.dead, 0, cap, e->stream));
     w.pairs_cap = 4096;
     NBE_HIP(hipMalloc((void**)&w.pairs, w.pairs_cap * sizeof(int2)));
-    NBE_HIP(hipHostMalloc((void**)&w.total_host, sizeof(uint32_t), hipHostMallocDefault));
+    NBE_HIP(hipHostMalloc((void**)&w.total_host, 4 * sizeof(uint32_t), hipHostMallocDefault));
     w.cap = cap;
     return NBE_OK;
 }
@@ -343,6 +411,17 @@ int collide_emit_nodes(nbe_engine* e)
     return NBE_OK;
 }
 
+// A rank of the key-range-distributed tree keeps the list of its searching bodies behind the pair buffer's bookkeeping.
+static RankQueue rank_queue(nbe_engine* e)
+{
+    RankQueue rq;
+    rq.list = e->dist ? e->cw.rank_list : nullptr;
+    rq.meta = e->cw.rank_meta;
+    rq.cap = RANK_QUEUE_CAP;
+    rq.rcap = e->cw.radius_cap;
+    return rq;
+}
+
 // The counting search, the scan of the counts and the copy of their total to the host, all queued and not waited for:
 // a caller that drives several engines queues this on each of them before it finishes any.
 template <typename R4>
@@ -356,12 +435,22 @@ static int collide_begin_t(nbe_engine* e, const void* force_pos)
     const double lox = e->cfg.bound_center[0] - 0.5 * W, loy = e->cfg.bound_center[1] - 0.5 * W,
                  loz = e->cfg.bound_center[2] - 0.5 * W;
     NBE_HIP(hipMemsetAsync(w.count, 0, ((size_t)n + 1) * 4, e->stream));
+    const RankQueue rq = rank_queue(e);
+    if (rq.list) NBE_HIP(hipMemsetAsync(rq.meta, 0, 4 * sizeof(uint32_t), e->stream));
     hipLaunchKernelGGL((collide_search_kernel<R4, false>), dim3(cdiv(n, 256)), dim3(256), 0, e->stream, w.cnodes, t.counters,
                        t.keys[0], (const R4*)force_pos, e->radius[cur], e->orig[e->orig_cur], t.cellcnt, lox, loy, loz, W, w.count,
-                       w.offset, w.pairs);
+                       w.offset, w.pairs, rq);
     NBE_HIP(hipGetLastError());
-    NBE_TRY(device_scan_u32(e, w.count, w.offset, (size_t)n + 1));
-    NBE_HIP(hipMemcpyAsync(w.total_host, w.offset + n, 4, hipMemcpyDeviceToHost, e->stream));
+    if (rq.list) {
+        hipLaunchKernelGGL(collide_rank_kernel, dim3(cdiv((size_t)rq.cap, 256)), dim3(256), 0, e->stream, rq.list, rq.meta, rq.cap,
+                           rq.list + rq.cap);
+        hipLaunchKernelGGL(collide_offsets_kernel, dim3(1), dim3(64), 0, e->stream, rq.list + rq.cap, rq.meta, rq.cap, w.offset);
+        NBE_HIP(hipGetLastError());
+        NBE_HIP(hipMemcpyAsync(w.total_host, rq.meta, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
+    } else {
+        NBE_TRY(device_scan_u32(e, w.count, w.offset, (size_t)n + 1));
+        NBE_HIP(hipMemcpyAsync(w.total_host + 1, w.offset + n, 4, hipMemcpyDeviceToHost, e->stream));
+    }
     w.begun = true;
     return NBE_OK;
 }
@@ -404,7 +493,16 @@ static int collide_and_update_t(nbe_engine* e, const void* force_pos)
     NBE_TRY(collide_begin(e));
     w.begun = false;
     NBE_HIP(hipStreamSynchronize(e->stream));
-    const uint32_t total = *w.total_host;
+    const RankQueue rq = rank_queue(e);
+    const uint32_t total = w.total_host[1];
+    if (rq.list && (w.total_host[2] & 1u)) {
+        nbe_set_error("a body's radius exceeds the cap of %g m given for collisions on the distributed tree (its search could reach another rank's bodies)", rq.rcap);
+        return NBE_E_UNSUPPORTED;
+    }
+    if (rq.list && (w.total_host[2] & 2u)) {
+        nbe_set_error("more than %d bodies of one rank queue collision pairs in one step", RANK_QUEUE_CAP);
+        return NBE_E_UNSUPPORTED;
+    }
     e->stats.collision_pairs = total;
     if (total > 0) {
         if ((size_t)total > w.pairs_cap) {
@@ -414,8 +512,8 @@ static int collide_and_update_t(nbe_engine* e, const void* force_pos)
         }
         hipLaunchKernelGGL((collide_search_kernel<R4, true>), grid, block, 0, e->stream, w.cnodes, t.counters, t.keys[0],
                            (const R4*)force_pos, e->radius[cur], e->orig[e->orig_cur], t.cellcnt, lox, loy, loz, W, w.count,
-                           w.offset, w.pairs);
-        hipLaunchKernelGGL((collide_merge_kernel<A4>), dim3(1), dim3(64), 0, e->stream, w.pairs, w.offset + n, (A4*)e->posm[cur],
+                           w.offset, w.pairs, rq);
+        hipLaunchKernelGGL((collide_merge_kernel<A4>), dim3(1), dim3(64), 0, e->stream, w.pairs, rq.list ? rq.meta + 1 : w.offset + n, (A4*)e->posm[cur],
                            (A4*)e->vel[cur], (A4*)e->acc, e->radius[cur], w.dead, mixed ? e->mirror[cur] : (float4*)nullptr,
                            t.counters);
         NBE_HIP(hipGetLastError());

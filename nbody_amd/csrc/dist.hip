@@ -47,6 +47,7 @@ struct TopCell {          // a cell that spans ranks
 
 struct DistState {
     int rank = 0, world = 1;
+    int rec_elems = 2;                  // elements of a migration record: position+mass, velocity+index, and with collisions on the radius
     size_t cap = 0;                     // body slots of this engine (== e->n)
     size_t live_hi = 0;                 // slots [0, live_hi) may hold bodies, everything behind is free
     std::vector<uint64_t> split;        // world + 1
@@ -150,8 +151,8 @@ extern "C" int nbe_dist_upload(nbe_engine* e, int rank, int world, size_t capaci
 {
     if (!e) { nbe_set_error("engine is NULL"); return NBE_E_INVALID; }
     if (e->multi) { nbe_set_error("nbe_dist_upload on an engine with num_devices > 1"); return NBE_E_UNSUPPORTED; }
-    if (e->cfg.mode != NBE_MODE_TREE || e->cfg.collisions || e->cfg.reference_quirks || e->cfg.walk_criterion != NBE_WALK_PER_BODY) {
-        nbe_set_error("the distributed tree needs tree mode, collisions off, the per-body criterion and no reference_quirks");
+    if (e->cfg.mode != NBE_MODE_TREE || e->cfg.reference_quirks || e->cfg.walk_criterion != NBE_WALK_PER_BODY) {
+        nbe_set_error("the distributed tree needs tree mode, the per-body criterion and no reference_quirks");
         return NBE_E_UNSUPPORTED;
     }
     if (world < 1 || world > DIST_MAX_WORLD || rank < 0 || rank >= world) { nbe_set_error("bad rank %d of %d", rank, world); return NBE_E_INVALID; }
@@ -191,8 +192,9 @@ extern "C" int nbe_dist_upload(nbe_engine* e, int rank, int world, size_t capaci
     NBE_HIP(hipMalloc((void**)&d->d_split, (W2 + 1) * 8));
     NBE_HIP(hipMalloc((void**)&d->d_counts, (2 * W2 + 1) * 4));
     NBE_HIP(hipHostMalloc((void**)&d->h_counts, (2 * W2 + 1) * 4, hipHostMallocDefault));
-    NBE_HIP(hipMalloc(&d->outbox, capacity * 2 * e->elem));
-    NBE_HIP(hipMalloc(&d->inbox, capacity * 2 * e->elem));
+    d->rec_elems = e->cfg.collisions ? 3 : 2;
+    NBE_HIP(hipMalloc(&d->outbox, capacity * (size_t)d->rec_elems * e->elem));
+    NBE_HIP(hipMalloc(&d->inbox, capacity * (size_t)d->rec_elems * e->elem));
     NBE_HIP(hipMalloc((void**)&d->free_slots, capacity * 4));
     NBE_HIP(hipMalloc((void**)&d->d_frags, NBE_DIST_MAX_FRAGMENTS * sizeof(nbe_fragment_t)));
     NBE_HIP(hipMalloc((void**)&d->d_nfrag, 2 * sizeof(int)));
@@ -249,7 +251,7 @@ extern "C" int nbe_dist_buffers(nbe_engine* e, nbe_dist_buffers_t* out)
     out->outbox = d->outbox; out->inbox = d->inbox;
     out->export_nodes = d->export_nodes; out->import_nodes = d->import_nodes;
     out->slots = d->cap; out->export_cap = d->export_cap; out->import_cap = d->import_cap;
-    out->record_bytes = (uint32_t)(2 * e->elem);
+    out->record_bytes = (uint32_t)((size_t)d->rec_elems * e->elem);
     out->node_bytes = (uint32_t)(e->force64 ? sizeof(NodeD) : sizeof(NodeF));
     return NBE_OK;
 }
@@ -306,8 +308,35 @@ extern "C" int nbe_dist_set_splitters(nbe_engine* e, const uint64_t* split)
     for (int r = 0; r < d->world; r++)
         if (split[r] > split[r + 1]) { nbe_set_error("splitters must not decrease"); return NBE_E_INVALID; }
     d->split.assign(split, split + d->world + 1);
+    if (e->cfg.collisions) {
+        // A collision search (tree.go:245-281) stays inside the cells around its body that are at most four radii wide.
+        // Splitters are moved down to the border of a cell at least that wide (for the largest radius allowed), so that
+        // every such cell lies on one rank and a rank's own tree shows a body all it can touch.  Every rank rounds alike.
+        int depth = 0;
+        while (depth < 21 && ldexp(e->cfg.bound_width, -(depth + 1)) >= 4.000001 * e->cw.radius_cap) depth++;
+        const uint64_t mask = depth >= 21 ? ~0ull : ~((1ull << (3 * (21 - depth))) - 1ull);
+        for (int r = 1; r < d->world; r++) d->split[(size_t)r] &= mask;
+    }
     NBE_HIP(hipMemcpyAsync(d->d_split, d->split.data(), (d->world + 1) * 8, hipMemcpyHostToDevice, e->stream));
     NBE_HIP(hipStreamSynchronize(e->stream));
+    return NBE_OK;
+}
+
+extern "C" int nbe_dist_set_radius(nbe_engine* e, const double* radius, double radius_cap)
+{
+    NBE_TRY(check_dist(e, "nbe_dist_set_radius"));
+    DistState* d = e->dist;
+    if (!e->cfg.collisions) { nbe_set_error("nbe_dist_set_radius needs an engine created with collisions on"); return NBE_E_INVALID; }
+    if (e->stats.steps != 0 || d->classified || d->built) { nbe_set_error("nbe_dist_set_radius comes right after nbe_dist_upload"); return NBE_E_INVALID; }
+    if (!(radius_cap > 0.0) || !std::isfinite(radius_cap)) { nbe_set_error("radius_cap must be positive"); return NBE_E_INVALID; }
+    const size_t n = d->live_hi;                      // the bodies of the upload, still in upload order
+    if (radius) {
+        for (size_t i = 0; i < n; i++)
+            if (!(radius[i] >= 0.0) || radius[i] > radius_cap) { nbe_set_error("radius[%zu] is negative, NaN or above the cap", i); return NBE_E_INVALID; }
+        if (n) NBE_HIP(hipMemcpyAsync(e->radius[e->cur], radius, n * sizeof(double), hipMemcpyHostToDevice, e->stream));
+        NBE_HIP(hipStreamSynchronize(e->stream));
+    }
+    e->cw.radius_cap = radius_cap;
     return NBE_OK;
 }
 
@@ -362,13 +391,26 @@ __device__ __forceinline__ void put_index(float4& v, uint32_t idx) { v.w = __uin
 __device__ __forceinline__ void put_index(double4& v, uint32_t idx) { v.w = (double)idx; }
 __device__ __forceinline__ uint32_t get_index(const float4& v) { return __float_as_uint(v.w); }
 __device__ __forceinline__ uint32_t get_index(const double4& v) { return (uint32_t)v.w; }
+// (the radius, a double, rides in the third element of a record: as two words of an fp32 element)
+__device__ __forceinline__ void put_radius(float4& r, double v)
+{
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    r.x = __uint_as_float((unsigned)b); r.y = __uint_as_float((unsigned)(b >> 32));
+}
+__device__ __forceinline__ void put_radius(double4& r, double v) { r.x = v; }
+__device__ __forceinline__ double get_radius(const float4& r)
+{
+    return __longlong_as_double((long long)(((unsigned long long)__float_as_uint(r.y) << 32) | __float_as_uint(r.x)));
+}
+__device__ __forceinline__ double get_radius(const double4& r) { return r.x; }
 
 template <typename R4, typename S4>
 __global__ __launch_bounds__(256) void pack_kernel(const R4* __restrict__ posk, S4* __restrict__ posm, S4* __restrict__ vel,
                                                    float4* __restrict__ mirror, const uint32_t* __restrict__ orig, int slots, double lox,
                                                    double loy, double loz, double W, const uint64_t* __restrict__ split, int world,
                                                    uint64_t own_lo, uint64_t own_hi, uint32_t* __restrict__ counts,
-                                                   S4* __restrict__ outbox, uint32_t* __restrict__ free_slots)
+                                                   S4* __restrict__ outbox, uint32_t* __restrict__ free_slots,
+                                                   const double* __restrict__ radius, int rec)
 {
     // places are handed out per workgroup: ranks within the workgroup in LDS, one reservation per destination in memory
     __shared__ uint32_t cnt[DIST_MAX_WORLD + 1], base[DIST_MAX_WORLD + 1];      // [world]: all destinations together
@@ -394,8 +436,9 @@ __global__ __launch_bounds__(256) void pack_kernel(const R4* __restrict__ posk, 
     const uint32_t at = base[dest] + mine;
     S4 p = posm[i], v = vel[i];
     put_index(v, orig[i]);
-    outbox[2 * (size_t)at] = p;
-    outbox[2 * (size_t)at + 1] = v;
+    outbox[(size_t)rec * at] = p;
+    outbox[(size_t)rec * at + 1] = v;
+    if (radius) { S4 r; r.x = 0; r.y = 0; r.z = 0; r.w = 0; put_radius(r, radius[i]); outbox[(size_t)rec * at + 2] = r; }
     free_slots[base[world] + mine_all] = (uint32_t)i;
     // the slot now holds a massless body parked outside the bound
     p.x = lox + 2.0 * W; p.y = loy + 2.0 * W; p.z = loz + 2.0 * W; p.w = 0;
@@ -431,7 +474,7 @@ static int classify_t(nbe_engine* e, uint32_t* send_counts)
         hipLaunchKernelGGL((pack_kernel<R4, S4>), dim3(cdiv(slots, 256)), dim3(256), 0, e->stream, posk, (S4*)e->posm[e->cur],
                            (S4*)e->vel[e->cur], e->cfg.precision == NBE_PREC_MIXED ? e->mirror[e->cur] : (float4*)nullptr,
                            e->orig[e->orig_cur], slots, lo[0], lo[1], lo[2], width, d->d_split, W, d->split[d->rank], d->split[d->rank + 1],
-                           d->d_counts, (S4*)d->outbox, d->free_slots);
+                           d->d_counts, (S4*)d->outbox, d->free_slots, (const double*)e->radius[e->cur], d->rec_elems);
         NBE_HIP(hipGetLastError());
         // a caller that has not given the engine its own stream reads the outbox on streams the engine knows nothing of
         if (e->stream == e->own_stream) NBE_HIP(hipStreamSynchronize(e->stream));
@@ -457,13 +500,15 @@ extern "C" int nbe_dist_classify(nbe_engine* e, uint32_t* send_counts)
 template <typename S4>
 __global__ __launch_bounds__(256) void append_kernel(const S4* __restrict__ inbox, int k, const uint32_t* __restrict__ free_slots,
                                                      int n_free, int tail, S4* __restrict__ posm, S4* __restrict__ vel,
-                                                     float4* __restrict__ mirror, uint32_t* __restrict__ orig)
+                                                     float4* __restrict__ mirror, uint32_t* __restrict__ orig,
+                                                     double* __restrict__ radius, int rec)
 {
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j >= k) return;
     const int slot = j < n_free ? (int)free_slots[j] : tail + (j - n_free);
-    const S4 p = inbox[2 * (size_t)j];
-    S4 v = inbox[2 * (size_t)j + 1];
+    const S4 p = inbox[(size_t)rec * j];
+    S4 v = inbox[(size_t)rec * j + 1];
+    if (radius) radius[slot] = get_radius(inbox[(size_t)rec * j + 2]);
     orig[slot] = get_index(v);
     v.w = 0;
     posm[slot] = p;
@@ -486,11 +531,11 @@ extern "C" int nbe_dist_receive(nbe_engine* e, size_t k)
         if (e->state64)
             hipLaunchKernelGGL((append_kernel<double4>), dim3(cdiv(k, 256)), dim3(256), 0, e->stream, (const double4*)d->inbox, (int)k,
                                d->free_slots, (int)d->n_free, (int)d->live_hi, (double4*)e->posm[e->cur], (double4*)e->vel[e->cur], mirror,
-                               e->orig[e->orig_cur]);
+                               e->orig[e->orig_cur], e->radius[e->cur], d->rec_elems);
         else
             hipLaunchKernelGGL((append_kernel<float4>), dim3(cdiv(k, 256)), dim3(256), 0, e->stream, (const float4*)d->inbox, (int)k,
                                d->free_slots, (int)d->n_free, (int)d->live_hi, (float4*)e->posm[e->cur], (float4*)e->vel[e->cur], mirror,
-                               e->orig[e->orig_cur]);
+                               e->orig[e->orig_cur], e->radius[e->cur], d->rec_elems);
         NBE_HIP(hipGetLastError());
     }
     d->live_hi += extra;
@@ -660,8 +705,8 @@ extern "C" int nbe_dist_build(nbe_engine* e, nbe_fragment_t* frags, int max, int
     if (e->n == 0) {
         NBE_HIP(hipMemsetAsync(e->tw.counters, 0, 16 * sizeof(int), e->stream));
     } else {
-        NBE_TRY(tree_sort_and_build(e));
-        NBE_TRY(collide_emit_geometry(e));
+        NBE_TRY(tree_sort_and_build(e));              // (with collisions on it also leaves the search's geometry records)
+        if (!e->cfg.collisions) NBE_TRY(collide_emit_geometry(e));
         hipLaunchKernelGGL(fragments_kernel, dim3(cdiv(2 * e->n, 256)), dim3(256), 0, e->stream, e->cw.cnodes, e->tw.counters,
                            (const Q4*)e->tw.prefixq, d->split[d->rank], d->split[d->rank + 1], d->d_frags, d->d_nfrag, d->d_frag_bodies);
         NBE_TRY(fragment_boxes(e, box_rows));
@@ -1193,10 +1238,15 @@ extern "C" int nbe_dist_advance(nbe_engine* e)
     int* counters = e->tw.counters;
     e->tw.nodes = d->let_nodes;
     e->tw.counters = d->let_counters;
-    const int rc = tree_forces(e, e->cur, 0, e->n, true, false, e->cur ^ 1);
+    const bool collide = e->cfg.collisions != 0;
+    const int rc = tree_forces(e, e->cur, 0, e->n, !collide, false, e->cur ^ 1);
     e->tw.nodes = nodes;
     e->tw.counters = counters;
     NBE_TRY(rc);
+    // Collisions (tree.go:245-281, main.go:151-167): the accelerations wait in the engine's buffer, and search, merges and
+    // update run over the rank's own tree: whatever a body can touch lies in a cell of at most four radii, which the aligned
+    // splitters keep on one rank (nbe_dist_set_splitters), and pairs that share a body share that cell.
+    if (collide) NBE_TRY(collide_and_update(e));
     e->cur ^= 1;
     e->prepared = false;
     d->assembled = false; d->built = false; d->exported = false;

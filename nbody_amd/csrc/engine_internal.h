@@ -106,7 +106,11 @@ struct CollWork {
     int2* pairs = nullptr;          // queue: (searching body, resident body) as sorted indices
     size_t pairs_cap = 0;
     uint8_t* dead = nullptr;        // per device slot: absorbed since the last sort
-    uint32_t* total_host = nullptr; // pinned: the number of queued pairs, read back between the counting and the filling search
+    uint32_t* total_host = nullptr; // pinned, 4 words: [1] the number of queued pairs, read back between the counting and the filling
+                                    // search; on a rank of the distributed tree also [0] the bodies that queue pairs and [2] error bits
+    uint4* rank_list = nullptr;     // distributed tree: the searching bodies of this rank, unordered and then in queue order
+    uint32_t* rank_meta = nullptr;  // ... and their bookkeeping (collide.hip, RankQueue)
+    double radius_cap = 32.0;       // ... and the largest radius its splitters' alignment allows
     bool begun = false;             // collide_begin has queued the counting search of this step
 };
 

@@ -202,8 +202,8 @@ int multi_create(const nbe_config* cfg, nbe_engine** out)
         nbe_set_error("collisions with num_devices > 1 need tree mode");
         return NBE_E_UNSUPPORTED;
     }
-    if (cfg->distributed && (cfg->mode != NBE_MODE_TREE || cfg->collisions || cfg->reference_quirks || cfg->walk_criterion != NBE_WALK_PER_BODY)) {
-        nbe_set_error("distributed = 1 needs tree mode, collisions off, the per-body criterion and no reference_quirks");
+    if (cfg->distributed && (cfg->mode != NBE_MODE_TREE || cfg->reference_quirks || cfg->walk_criterion != NBE_WALK_PER_BODY)) {
+        nbe_set_error("distributed = 1 needs tree mode, the per-body criterion and no reference_quirks");
         return NBE_E_UNSUPPORTED;
     }
     nbe_engine* e = new (std::nothrow) nbe_engine();
@@ -683,9 +683,15 @@ int multi_dist_stats(nbe_engine* e, nbe_stats_t* out)
     memset(out, 0, sizeof(*out));
     out->n = m->dist->n_total;
     for (nbe_engine* s : m->subs) {
+        if (e->cfg.collisions) {
+            nbe_stats_t st;
+            NBE_TRY(nbe_stats(s, &st));           // (reads the GPU's counts: bodies absorbed since its last build)
+            out->merges += st.merges;
+        }
         out->n_alive += s->stats.n_alive;
         out->tree_nodes += s->stats.tree_nodes;
         out->tree_cells += s->stats.tree_cells;
+        out->collision_pairs += s->stats.collision_pairs;
     }
     out->steps = m->subs[0]->stats.steps;
     return NBE_OK;
@@ -726,7 +732,26 @@ int multi_upload(nbe_engine* e, size_t n, const double* pos, const double* vel, 
 
 int multi_set_radius(nbe_engine* e, const double* radius)
 {
-    for (nbe_engine* s : e->multi->subs) NBE_TRY(nbe_set_radius(s, radius));
+    MultiState* m = e->multi;
+    if (m->dist) {
+        // every GPU takes the radii of the bodies it was handed at the upload, and all agree on the largest radius a body
+        // may grow to (sixteen times the largest given, at least 32 m): the splitters are then chosen anew, aligned for it
+        DistMulti* d = m->dist;
+        const size_t G = m->subs.size(), n = d->n_total, per = (n + G - 1) / G;
+        if (m->subs[0]->stats.steps != 0 || d->prepared) { nbe_set_error("with distributed = 1, nbe_set_radius comes right after nbe_upload"); return NBE_E_INVALID; }
+        double cap = 2.0;
+        for (size_t i = 0; i < n; i++) {
+            if (!(radius[i] >= 0.0)) { nbe_set_error("radius[%zu] is negative or NaN", i); return NBE_E_INVALID; }
+            cap = std::max(cap, radius[i]);
+        }
+        cap *= 16.0;
+        NBE_TRY(d->pool.run([&](int r) -> int {
+            const size_t a = std::min(n, (size_t)r * per);
+            return nbe_dist_set_radius(m->subs[(size_t)r], radius + a, cap);
+        }));
+        return dist_distribute(e);
+    }
+    for (nbe_engine* s : m->subs) NBE_TRY(nbe_set_radius(s, radius));
     return NBE_OK;
 }
 

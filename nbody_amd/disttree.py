@@ -46,6 +46,7 @@ def _declare(lib):
     lib.nbe_dist_sample_keys.argtypes = [vp, C.c_size_t, u64p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
     lib.nbe_dist_set_splitters.argtypes = [vp, u64p]
     lib.nbe_dist_set_total_mass.argtypes = [vp, C.c_double]
+    lib.nbe_dist_set_radius.argtypes = [vp, dp, C.c_double]
     lib.nbe_dist_buffers.argtypes = [vp, C.POINTER(DistBuffers)]
     lib.nbe_dist_classify.argtypes = [vp, C.POINTER(C.c_uint32)]
     lib.nbe_dist_receive.argtypes = [vp, C.c_size_t]
@@ -83,7 +84,7 @@ def layout(all_frags, sizes):
     return tops[:nt.value].copy(), dst[:n].copy(), total.value
 
 
-DIST_EXPORTS = ["nbe_dist_layout", "nbe_dist_energy", "nbe_dist_set_total_mass", "nbe_dist_upload", "nbe_dist_sample_keys", "nbe_dist_set_splitters", "nbe_dist_buffers", "nbe_dist_classify",
+DIST_EXPORTS = ["nbe_dist_layout", "nbe_dist_energy", "nbe_dist_set_total_mass", "nbe_dist_set_radius", "nbe_dist_upload", "nbe_dist_sample_keys", "nbe_dist_set_splitters", "nbe_dist_buffers", "nbe_dist_classify",
                 "nbe_dist_receive", "nbe_dist_build", "nbe_dist_export", "nbe_dist_assemble", "nbe_dist_advance",
                 "nbe_dist_download"]
 
@@ -150,6 +151,12 @@ class DistRank:
         self._check(self._lib.nbe_dist_sample_keys(self._h, max_samples, keys.ctypes.data_as(C.POINTER(C.c_uint64)),
                                                    C.byref(cnt), C.byref(live)))
         return keys[:cnt.value], live.value
+
+    def set_radius(self, radius, radius_cap=32.0):
+        """Collisions on: the radii of the uploaded bodies (None keeps the reference's 2 m) and the largest radius any body
+        of the run may reach, the same on every rank; right after upload()."""
+        r = None if radius is None else np.ascontiguousarray(radius, dtype=np.float64).reshape(-1)
+        self._check(self._lib.nbe_dist_set_radius(self._h, None if r is None else _dp(r), float(radius_cap)))
 
     def set_total_mass(self, total):
         """The run's total mass (all ranks, the same value everywhere): the quantum of the exact cell sums follows from it."""

@@ -11,7 +11,7 @@
 static double frand(unsigned *s) { *s = *s * 1664525u + 1013904223u; return (double)(*s >> 8) / 16777216.0; }
 
 /* distributed: 0 = every shard holds all bodies; 1 = every body on one shard only (cfg.distributed; one shard: the
- * same cell sums on one engine, cfg.cell_sums = NBE_SUMS_TREE, which is what a distributed run must reproduce) */
+ * same cell sums on one engine, cfg.cell_sums = NBE_SUMS_EXACT, which is what a distributed run must reproduce) */
 static int run_as(int mode, int precision, int shards, int distributed, double *pos_out, double *vel_out);
 static int run(int mode, int precision, int shards, double *pos_out, double *vel_out) { return run_as(mode, precision, shards, 0, pos_out, vel_out); }
 
@@ -34,7 +34,7 @@ static int run_as(int mode, int precision, int shards, int distributed, double *
     if (nbe_default_config(&cfg) != NBE_OK) return 20;
     cfg.mode = mode; cfg.precision = precision; cfg.theta = 0.6;
     if (shards > 1) { cfg.num_devices = shards; cfg.device_ids = ids; cfg.distributed = distributed; }
-    else if (distributed) cfg.cell_sums = NBE_SUMS_TREE;
+    else if (distributed) cfg.cell_sums = NBE_SUMS_EXACT;
     if (nbe_create(&cfg, &e) != NBE_OK) { printf("create: %s\n", nbe_last_error()); return 21; }
     if (nbe_upload(e, N, pos, vel, mass, NULL) != NBE_OK) { printf("upload: %s\n", nbe_last_error()); return 22; }
     if (nbe_step(e, 7) != NBE_OK) { printf("step: %s\n", nbe_last_error()); return 23; }

@@ -131,7 +131,7 @@ def test_bodies_that_leave_the_bound_are_dropped_on_their_rank(gpu):
 
 def test_call_order_and_unsupported_configurations(gpu):
     b = physics.plummer(500, seed=1, a=2e3)
-    for kw in (dict(collisions=True), dict(per_wave=True), dict(ref_com=True)):
+    for kw in (dict(per_wave=True), dict(ref_com=True)):
         r = DistRank(0, 2, **kw)
         with pytest.raises(EngineError, match="distributed tree needs"):
             r.upload(1000, b.pos, b.vel, b.mass, 0)
@@ -371,7 +371,7 @@ def test_distributed_needs_several_devices_and_tree_mode(gpu):
     with pytest.raises(EngineError, match="needs tree mode"):
         Engine(mode="direct", devices=[0, 0], distributed=True)
     with pytest.raises(EngineError, match="needs tree mode"):
-        Engine(mode="tree", devices=[0, 0], distributed=True, collisions=True)
+        Engine(mode="tree", devices=[0, 0], distributed=True, per_wave=True)
 
 
 def test_a_rank_can_be_loaded_again(gpu):
@@ -395,3 +395,90 @@ def test_a_rank_can_be_loaded_again(gpu):
     finally:
         for r in ranks:
             r.close()
+
+
+@pytest.mark.parametrize("precision,world", [("f64", 3), ("f32", 4)])
+def test_collisions_on_the_distributed_tree_equal_one_engine(gpu, precision, world):
+    """The reference's default run has collisions on (main.go:24, 151-167; tree.go:245-281).  A crowded scene over 20
+    steps on several ranks against one engine: every step's queue length, the merges so far and the bodies left are
+    equal, and so are the survivors' identities, masses, positions and velocities at the end, bit for bit (both sum their
+    cells exactly, so the forces are the same bits, and every rank merges its own pairs in the reference's queue order).
+    The splitters are aligned to cells of at least four times the radius cap, here 64 m cells."""
+    rng = np.random.default_rng(5)
+    n = 6000
+    pos = rng.uniform(-150.0, 150.0, (n, 3))
+    vel = rng.normal(0, 1e-3, (n, 3))
+    mass = np.abs(rng.normal(1e3, 500, n)) + 1
+    rad = rng.uniform(0.5, 3.0, n)
+    nsteps, cap = 20, 8.0
+    kw = dict(precision=precision, theta=0.7, dt=50.0)
+    want_steps = []
+    with Engine(mode="tree", collisions=True, exact_sums=True, **kw) as e:
+        e.upload(pos, vel, mass)
+        e.set_radius(rad)
+        for _ in range(nsteps):
+            e.step(1)
+            st = e.stats()
+            want_steps.append((int(st.collision_pairs), int(st.merges), int(st.n_alive)))
+        wp, wv, wm, wid = e.download()
+    assert want_steps[-1][1] > 100                                  # the scene does collide
+    per = (n + world - 1) // world
+    ranks = [DistRank(r, world, collisions=True, **kw) for r in range(world)]
+    got_steps = []
+    try:
+        for r in ranks:
+            a, z = min(n, r.rank * per), min(n, (r.rank + 1) * per)
+            r.upload(int(per * 2.5) + 1024, pos[a:z], vel[a:z], mass[a:z], a)
+            r.set_radius(rad[a:z], cap)
+            r.use_torch_stream()
+        dt = DistributedTree(ranks, LocalComm(world))
+        dt.distribute()
+        for _ in range(nsteps):
+            dt.step(1)
+            sts = [r.engine.stats() for r in ranks]
+            got_steps.append((sum(int(s.collision_pairs) for s in sts), sum(int(s.merges) for s in sts), sum(int(s.n_alive) for s in sts)))
+        idx, p, v, m = dt.download()
+    finally:
+        for r in ranks:
+            r.close()
+    assert got_steps == want_steps
+    assert np.array_equal(idx, wid) and np.array_equal(m, wm)
+    assert np.array_equal(p, wp) and np.array_equal(v, wv)
+
+
+def test_collisions_behind_one_handle_and_a_radius_above_the_cap(gpu):
+    """Engine(devices=[0, 0, 0], distributed=True, collisions=True): the engine drives the ranks itself; the same merges
+    and survivors as one engine.  Radii above the cap, or given after the run has started, are refused."""
+    rng = np.random.default_rng(9)
+    n = 4000
+    pos = rng.uniform(-100.0, 100.0, (n, 3)); vel = rng.normal(0, 1e-3, (n, 3))
+    mass = np.abs(rng.normal(1e3, 500, n)) + 1; rad = rng.uniform(0.5, 3.0, n)
+    kw = dict(mode="tree", precision="f64", theta=0.7, dt=50.0, collisions=True)
+    with Engine(exact_sums=True, **kw) as one:
+        one.upload(pos, vel, mass); one.set_radius(rad)
+        one.step(10)
+        want, wst = one.download(), one.stats()
+    with Engine(devices=[0, 0, 0], distributed=True, **kw) as e:
+        e.upload(pos, vel, mass); e.set_radius(rad)
+        e.step(10)
+        got, gst = e.download(), e.stats()
+        with pytest.raises(EngineError, match="right after"):
+            e.set_radius(rad)
+    assert wst.merges > 10 and gst.merges == wst.merges and gst.n_alive == wst.n_alive
+    for a, w in zip(got, want):
+        assert np.array_equal(a, w)
+    r = DistRank(0, 1, precision="f32", collisions=True)
+    try:
+        r.upload(2000, pos[:1000], vel[:1000], mass[:1000], 0)
+        big = rad[:1000].copy(); big[7] = 5.0
+        with pytest.raises(EngineError, match="above the cap"):
+            r.set_radius(big, 4.0)
+        r.set_radius(big, 6.0)
+        r.use_torch_stream()
+        dt = DistributedTree([r], LocalComm(1))
+        dt.distribute()
+        dt.step(1)
+        with pytest.raises(EngineError, match="right after"):
+            r.set_radius(big, 6.0)
+    finally:
+        r.close()
