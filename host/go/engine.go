@@ -76,7 +76,7 @@ func newGPUEngine(tree, nocollision bool, theta, dt float64, opt gpuOptions) *gp
 	if opt.gpus > 1 {
 		cfg.num_devices = C.int(opt.gpus) // device_ids stays nil: devices 0 .. gpus-1
 		if opt.distributed {
-			cfg.distributed = 1 // every body on one GPU only; needs -tree -nocollision
+			cfg.distributed = 1 // every body on one GPU only; needs -tree
 		}
 	}
 	if tree && opt.asGo {

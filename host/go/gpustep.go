@@ -22,7 +22,7 @@ var (
 	gpuPerWave   = flag.Bool("perwave", false, "tree mode: the bodies of a wavefront open cells together (not the reference's interaction set)")
 	gpuCount     = flag.Int("gpus", 1, "GPUs driven by the one engine (with collisions on: -tree only)")
 	gpuBlocking  = flag.Bool("blockingframes", false, "take frames with a blocking download instead of the side-stream ring")
-	gpuDist      = flag.Bool("distributed", false, "with -gpus N -tree -nocollision: every body on one GPU only, pruned subtrees exchanged")
+	gpuDist      = flag.Bool("distributed", false, "with -gpus N -tree: every body on one GPU only, pruned subtrees exchanged")
 )
 
 func gpuOptionsFromFlags() gpuOptions {

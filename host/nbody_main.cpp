@@ -336,7 +336,7 @@ int main(int argc, char** argv)
     cfg.collisions = nocollision ? 0 : 1;                    // main.go:24
     cfg.num_devices = gpus;                                  // > 1: devices 0 .. gpus-1 (with collisions on: -tree only)
     if (!devices.empty()) cfg.device_ids = devices.data();
-    // -distributed (with -gpus N -tree -nocollision): every body on one GPU only, pruned subtrees exchanged
+    // -distributed (with -gpus N -tree): every body on one GPU only, pruned subtrees exchanged
     cfg.distributed = distributed ? 1 : 0;
     // -asgo: the tree path with the Go program's own arithmetic (running cell centres tree.go:189-193, last
     // n mod 4 bodies unwalked main.go:134-148), for comparing a run with the reference number for number

@@ -445,6 +445,18 @@ static void dist_frames_deliver(nbe_engine* e)
         }
         DistFrameSlot& s = fs.slots[(size_t)slot];
         for (hipEvent_t ev : s.done) (void)hipEventSynchronize(ev);
+        if (e->cfg.collisions) {
+            // a body absorbed in the previous step still holds its slot until its GPU's next build: massless and parked
+            // outside the bound (collide_update_kernel); it is no body of the frame (main.go:91-95 skips the nil entries)
+            const float parked = (float)(e->cfg.bound_center[0] + 1.5 * e->cfg.bound_width);
+            size_t keep = 0;
+            for (size_t k = 0; k < s.n; k++) {
+                if (s.xyzm[4 * k + 3] == 0.0f && s.xyzm[4 * k] == parked) continue;
+                if (keep != k) { memcpy(s.xyzm + 4 * keep, s.xyzm + 4 * k, 4 * sizeof(float)); s.orig[keep] = s.orig[k]; }
+                keep++;
+            }
+            s.n = keep;
+        }
         fs.ids_scratch.resize(s.n);
         for (size_t k = 0; k < s.n; k++) fs.ids_scratch[k] = s.orig[k] < d->ids.size() ? d->ids[s.orig[k]] : (uint64_t)s.orig[k];
         fs.cb(fs.user, s.frame, s.n, s.xyzm, nullptr, fs.ids_scratch.data());

@@ -454,19 +454,29 @@ def test_collisions_behind_one_handle_and_a_radius_above_the_cap(gpu):
     pos = rng.uniform(-100.0, 100.0, (n, 3)); vel = rng.normal(0, 1e-3, (n, 3))
     mass = np.abs(rng.normal(1e3, 500, n)) + 1; rad = rng.uniform(0.5, 3.0, n)
     kw = dict(mode="tree", precision="f64", theta=0.7, dt=50.0, collisions=True)
+    frames_one, frames_dist = [], []
     with Engine(exact_sums=True, **kw) as one:
         one.upload(pos, vel, mass); one.set_radius(rad)
+        one.frame_stream_begin(lambda f, xyzm, ids, radius: frames_one.append((f, np.sort(ids))), every=2, slots=3)
         one.step(10)
+        one.frame_stream_end()
         want, wst = one.download(), one.stats()
     with Engine(devices=[0, 0, 0], distributed=True, **kw) as e:
         e.upload(pos, vel, mass); e.set_radius(rad)
+        e.frame_stream_begin(lambda f, xyzm, ids, radius: frames_dist.append((f, np.sort(ids))), every=2, slots=3)
         e.step(10)
+        e.frame_stream_end()
         got, gst = e.download(), e.stats()
         with pytest.raises(EngineError, match="right after"):
             e.set_radius(rad)
     assert wst.merges > 10 and gst.merges == wst.merges and gst.n_alive == wst.n_alive
     for a, w in zip(got, want):
         assert np.array_equal(a, w)
+    # the frames hold the bodies that are left, absorbed ones gone at once (main.go:91-95)
+    assert [f for f, _ in frames_dist] == [f for f, _ in frames_one] == [0, 1, 2, 3, 4]
+    for (_, a), (_, w) in zip(frames_dist, frames_one):
+        assert np.array_equal(a, w)
+    assert len(frames_one[-1][1]) < n
     r = DistRank(0, 1, precision="f32", collisions=True)
     try:
         r.upload(2000, pos[:1000], vel[:1000], mass[:1000], 0)
