@@ -492,3 +492,43 @@ def test_collisions_behind_one_handle_and_a_radius_above_the_cap(gpu):
             r.set_radius(big, 6.0)
     finally:
         r.close()
+
+
+@pytest.mark.parametrize("scene", ["mass_ratio", "tiny_masses", "huge_masses", "offset_bound", "massless"])
+def test_exact_cell_sums_hold_for_extreme_scenes(gpu, scene):
+    """NBE_SUMS_EXACT quantises every body's mass and moments to 2^-126 of (total mass x the bound's reach): the cells of
+    fp64 node records must come out as the child-by-child fp64 sums do, to a few ulps, whatever the spread of the masses,
+    their scale, or where the bound sits; and a permutation of the upload order must not change one bit of them."""
+    rng = np.random.default_rng(42)
+    n = 20000
+    kw = dict(mode="tree", precision="f64", theta=0.5)
+    pos = rng.normal(0, 3e3, (n, 3)).clip(-3e4, 3e4)
+    mass = np.abs(rng.normal(1e3, 300, n)) + 1
+    if scene == "mass_ratio":
+        mass[::1000] = 1e15                      # 20 bodies outweigh the rest by twelve orders of magnitude
+    elif scene == "tiny_masses":
+        mass *= 1e-25
+    elif scene == "huge_masses":
+        mass *= 1e22
+    elif scene == "offset_bound":
+        pos = pos * 0.01 + np.array([5e5, -2e5, 7e5])
+        kw.update(bound_center=[5e5, -2e5, 7e5], bound_width=3000.0)
+    elif scene == "massless":
+        mass[rng.random(n) < 0.3] = 0.0
+    tabs = []
+    for extra in (dict(tree_sums=True), dict(exact_sums=True)):
+        with Engine(**kw, **extra) as e:
+            e.upload(pos, np.zeros_like(pos), mass)
+            tabs.append(e.tree_nodes())
+    t, x = tabs
+    assert t.shape == x.shape and np.array_equal(t[:, 4:], x[:, 4:])
+    cells = t[:, 4] > 0
+    assert np.abs(x[cells, 3] - t[cells, 3]).max() <= 1e-13 * t[cells, 3].max()
+    heavy = cells & (t[:, 3] > 0)
+    scale = np.abs(pos).max()
+    assert np.abs(x[heavy, :3] - t[heavy, :3]).max() <= 1e-12 * scale
+    perm = rng.permutation(n)
+    with Engine(**kw, exact_sums=True) as e:
+        e.upload(pos[perm], np.zeros_like(pos), mass[perm])
+        y = e.tree_nodes()
+    assert np.array_equal(x[cells], y[cells])
