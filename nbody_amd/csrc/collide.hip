@@ -467,16 +467,6 @@ int collide_begin(nbe_engine* e)
     return NBE_E_INVALID;
 }
 
-int collide_emit_geometry(nbe_engine* e)
-{
-    TreeWork& t = e->tw;
-    const int n = (int)e->n;
-    hipLaunchKernelGGL(emit_cnodes_kernel, dim3(cdiv(2 * (size_t)n, 256)), dim3(256), 0, e->stream, n, t.counters, t.keys[0],
-                       t.bt_first, t.bt_last, t.bt_parent, t.bt_level, t.lvlmask, t.cellcnt, e->cw.cnodes);
-    NBE_HIP(hipGetLastError());
-    return NBE_OK;
-}
-
 template <typename R4, typename A4, typename A>
 static int collide_and_update_t(nbe_engine* e, const void* force_pos)
 {

@@ -52,11 +52,12 @@ struct DistState {
     size_t live_hi = 0;                 // slots [0, live_hi) may hold bodies, everything behind is free
     std::vector<uint64_t> split;        // world + 1
     uint64_t* d_split = nullptr;
-    uint32_t* d_counts = nullptr;       // [0, world) bodies leaving per destination, [world, 2 world) pack cursors, [2 world] freed slots
+    uint32_t* d_counts = nullptr;       // the counters of a migration, see counts_starts / counts_cursors
     uint32_t* h_counts = nullptr;       // pinned copy
     void* outbox = nullptr;
     void* inbox = nullptr;
     uint32_t* free_slots = nullptr;     // slots vacated by the last classify
+    uint16_t* dest_of = nullptr;        // per slot, left by the last classify: 0 = stays (or no body), d + 1 = moves to rank d
     uint32_t n_free = 0;
     int frag_hint = 0;                  // fragments of the last build (sizes the grid of the next build's box kernel)
     bool classified = false, built = false, exported = false, assembled = false, have_total = false;
@@ -99,6 +100,14 @@ struct DistState {
     size_t seg_cap = 0, top_cap = 0;
 };
 
+// Layout of the counters of a migration (32-word stretches, so that the words the pack pass hammers with atomics share no
+// cache line with the ones it only reads): [0, world) the leavers per destination as classify_kernel counted them;
+// [A, A + world) where each destination's stretch of the outbox starts; [B, B + world] running cursors within the
+// stretches, then the freed slots.
+__host__ __device__ static inline int counts_starts(int world) { return (world + 31) / 32 * 32; }
+__host__ __device__ static inline int counts_cursors(int world) { return 2 * ((world + 31) / 32 * 32); }
+static inline size_t counts_words(int world) { return (size_t)counts_cursors(world) + (size_t)world + 1; }
+
 static int dfree(void** p)
 {
     if (*p) { NBE_HIP(hipFree(*p)); *p = nullptr; }
@@ -109,7 +118,7 @@ void dist_destroy(nbe_engine* e)
 {
     DistState* d = e->dist;
     if (!d) return;
-    void** dev[] = {(void**)&d->d_split, (void**)&d->d_counts, &d->outbox, &d->inbox, (void**)&d->free_slots, (void**)&d->d_frags,
+    void** dev[] = {(void**)&d->d_split, (void**)&d->d_counts, &d->outbox, &d->inbox, (void**)&d->free_slots, (void**)&d->dest_of, (void**)&d->d_frags,
                     (void**)&d->d_nfrag, (void**)&d->d_aabb, (void**)&d->x_diff, (void**)&d->x_cover, (void**)&d->x_flag,
                     (void**)&d->x_index, (void**)&d->d_seg_first, &d->export_nodes, (void**)&d->d_export_base, (void**)&d->d_export_sizes,
                     (void**)&d->d_boxes, (void**)&d->d_frag_bodies, (void**)&d->d_box_counts, &d->import_nodes, &d->let_nodes, (void**)&d->let_counters, (void**)&d->d_segments,
@@ -190,12 +199,13 @@ extern "C" int nbe_dist_upload(nbe_engine* e, int rank, int world, size_t capaci
     const size_t nodes2 = 2 * capacity + 2;
     const size_t node_bytes = e->force64 ? sizeof(NodeD) : sizeof(NodeF);
     NBE_HIP(hipMalloc((void**)&d->d_split, (W2 + 1) * 8));
-    NBE_HIP(hipMalloc((void**)&d->d_counts, (2 * W2 + 1) * 4));
+    NBE_HIP(hipMalloc((void**)&d->d_counts, counts_words(world) * 4));
     NBE_HIP(hipHostMalloc((void**)&d->h_counts, (2 * W2 + 1) * 4, hipHostMallocDefault));
     d->rec_elems = e->cfg.collisions ? 3 : 2;
     NBE_HIP(hipMalloc(&d->outbox, capacity * (size_t)d->rec_elems * e->elem));
     NBE_HIP(hipMalloc(&d->inbox, capacity * (size_t)d->rec_elems * e->elem));
     NBE_HIP(hipMalloc((void**)&d->free_slots, capacity * 4));
+    NBE_HIP(hipMalloc((void**)&d->dest_of, capacity * sizeof(uint16_t)));
     NBE_HIP(hipMalloc((void**)&d->d_frags, NBE_DIST_MAX_FRAGMENTS * sizeof(nbe_fragment_t)));
     NBE_HIP(hipMalloc((void**)&d->d_nfrag, 2 * sizeof(int)));
     NBE_HIP(hipHostMalloc((void**)&d->h_frags, NBE_DIST_MAX_FRAGMENTS * sizeof(nbe_fragment_t), hipHostMallocDefault));
@@ -368,7 +378,7 @@ __device__ __forceinline__ int owner_of(const uint64_t* __restrict__ split, int 
 template <typename R4>
 __global__ __launch_bounds__(256) void classify_kernel(const R4* __restrict__ posk, int slots, double lox, double loy, double loz, double W,
                                                        const uint64_t* __restrict__ split, int world, uint64_t own_lo, uint64_t own_hi,
-                                                       uint32_t* __restrict__ counts)
+                                                       uint32_t* __restrict__ counts, uint16_t* __restrict__ dest_of)
 {
     __shared__ uint32_t cnt[DIST_MAX_WORLD];
     for (int t = threadIdx.x; t < world; t += 256) cnt[t] = 0;
@@ -378,7 +388,13 @@ __global__ __launch_bounds__(256) void classify_kernel(const R4* __restrict__ po
         const R4 p = posk[i];
         const uint64_t key = body_key((double)p.x, (double)p.y, (double)p.z, lox, loy, loz, W);
         // (nearly every body stays: no search for those)
-        if (key != KEY_DEAD && !(key >= own_lo && key < own_hi)) atomicAdd(&cnt[owner_of(split, world, key)], 1u);
+        uint16_t to = 0;
+        if (key != KEY_DEAD && !(key >= own_lo && key < own_hi)) {
+            const int dest = owner_of(split, world, key);
+            atomicAdd(&cnt[dest], 1u);
+            to = (uint16_t)(dest + 1);
+        }
+        dest_of[i] = to;                              // the pack pass reads this instead of making the key again
     }
     __syncthreads();
     for (int t = threadIdx.x; t < world; t += 256)
@@ -404,48 +420,67 @@ __device__ __forceinline__ double get_radius(const float4& r)
 }
 __device__ __forceinline__ double get_radius(const double4& r) { return r.x; }
 
-template <typename R4, typename S4>
-__global__ __launch_bounds__(256) void pack_kernel(const R4* __restrict__ posk, S4* __restrict__ posm, S4* __restrict__ vel,
+// (layout of `counts`: counts_starts / counts_cursors near the top of the file)
+
+__global__ __launch_bounds__(64) void pack_starts_kernel(uint32_t* __restrict__ counts, int world)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    uint32_t run = 0;
+    for (int q = 0; q < world; q++) { counts[counts_starts(world) + q] = run; run += counts[q]; }
+}
+
+// A workgroup packs the leavers among 1024 slots (four per thread): places are handed out per workgroup, ranks within
+// the workgroup in LDS, one reservation per destination in memory.
+#define PACK_SLOTS 4
+template <typename S4>
+__global__ __launch_bounds__(256) void pack_kernel(const uint16_t* __restrict__ dest_of, S4* __restrict__ posm, S4* __restrict__ vel,
                                                    float4* __restrict__ mirror, const uint32_t* __restrict__ orig, int slots, double lox,
-                                                   double loy, double loz, double W, const uint64_t* __restrict__ split, int world,
-                                                   uint64_t own_lo, uint64_t own_hi, uint32_t* __restrict__ counts,
+                                                   double loy, double loz, double W, int world, uint32_t* __restrict__ counts,
                                                    S4* __restrict__ outbox, uint32_t* __restrict__ free_slots,
                                                    const double* __restrict__ radius, int rec)
 {
-    // places are handed out per workgroup: ranks within the workgroup in LDS, one reservation per destination in memory
     __shared__ uint32_t cnt[DIST_MAX_WORLD + 1], base[DIST_MAX_WORLD + 1];      // [world]: all destinations together
+    int dest[PACK_SLOTS];
+    bool any = false;
+#pragma unroll
+    for (int k = 0; k < PACK_SLOTS; k++) {
+        const int i = (blockIdx.x * PACK_SLOTS + k) * 256 + threadIdx.x;
+        dest[k] = i < slots ? (int)dest_of[i] - 1 : -1;
+        any = any || dest[k] >= 0;
+    }
+    if (__syncthreads_or(any) == 0) return;           // nobody of these slots leaves
     for (int t = threadIdx.x; t <= world; t += 256) cnt[t] = 0;
     __syncthreads();
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    int dest = -1;
-    uint32_t mine = 0, mine_all = 0;
-    if (i < slots) {
-        const R4 pk = posk[i];
-        const uint64_t key = body_key((double)pk.x, (double)pk.y, (double)pk.z, lox, loy, loz, W);
-        if (key != KEY_DEAD && !(key >= own_lo && key < own_hi)) {
-            dest = owner_of(split, world, key);
-            mine = atomicAdd(&cnt[dest], 1u);
-            mine_all = atomicAdd(&cnt[world], 1u);
+    uint32_t mine[PACK_SLOTS], mine_all[PACK_SLOTS];
+#pragma unroll
+    for (int k = 0; k < PACK_SLOTS; k++)
+        if (dest[k] >= 0) {
+            mine[k] = atomicAdd(&cnt[dest[k]], 1u);
+            mine_all[k] = atomicAdd(&cnt[world], 1u);
         }
-    }
     __syncthreads();
+    const int S = counts_starts(world), C = counts_cursors(world);
     for (int t = threadIdx.x; t <= world; t += 256)
-        if (cnt[t]) base[t] = atomicAdd(&counts[t == world ? 2 * world : world + t], cnt[t]);
+        if (cnt[t]) base[t] = (t < world ? counts[S + t] : 0u) + atomicAdd(&counts[C + t], cnt[t]);
     __syncthreads();
-    if (dest < 0) return;
-    const uint32_t at = base[dest] + mine;
-    S4 p = posm[i], v = vel[i];
-    put_index(v, orig[i]);
-    outbox[(size_t)rec * at] = p;
-    outbox[(size_t)rec * at + 1] = v;
-    if (radius) { S4 r; r.x = 0; r.y = 0; r.z = 0; r.w = 0; put_radius(r, radius[i]); outbox[(size_t)rec * at + 2] = r; }
-    free_slots[base[world] + mine_all] = (uint32_t)i;
-    // the slot now holds a massless body parked outside the bound
-    p.x = lox + 2.0 * W; p.y = loy + 2.0 * W; p.z = loz + 2.0 * W; p.w = 0;
-    v.x = 0; v.y = 0; v.z = 0; v.w = 0;
-    posm[i] = p;
-    vel[i] = v;
-    if (mirror) mirror[i] = make_float4((float)p.x, (float)p.y, (float)p.z, 0.0f);
+#pragma unroll
+    for (int k = 0; k < PACK_SLOTS; k++) {
+        if (dest[k] < 0) continue;
+        const int i = (blockIdx.x * PACK_SLOTS + k) * 256 + threadIdx.x;
+        const uint32_t at = base[dest[k]] + mine[k];
+        S4 p = posm[i], v = vel[i];
+        put_index(v, orig[i]);
+        outbox[(size_t)rec * at] = p;
+        outbox[(size_t)rec * at + 1] = v;
+        if (radius) { S4 r; r.x = 0; r.y = 0; r.z = 0; r.w = 0; put_radius(r, radius[i]); outbox[(size_t)rec * at + 2] = r; }
+        free_slots[base[world] + mine_all[k]] = (uint32_t)i;
+        // the slot now holds a massless body parked outside the bound
+        p.x = lox + 2.0 * W; p.y = loy + 2.0 * W; p.z = loz + 2.0 * W; p.w = 0;
+        v.x = 0; v.y = 0; v.z = 0; v.w = 0;
+        posm[i] = p;
+        vel[i] = v;
+        if (mirror) mirror[i] = make_float4((float)p.x, (float)p.y, (float)p.z, 0.0f);
+    }
 }
 
 template <typename R4, typename S4>
@@ -457,28 +492,27 @@ static int classify_t(nbe_engine* e, uint32_t* send_counts)
     bound_lo(e, lo, &width);
     const int slots = (int)d->live_hi;
     const R4* posk = (const R4*)key_positions(e);
-    NBE_HIP(hipMemsetAsync(d->d_counts, 0, (2 * (size_t)W + 1) * 4, e->stream));
+    NBE_HIP(hipMemsetAsync(d->d_counts, 0, counts_words(W) * 4, e->stream));
     if (slots > 0) {
         hipLaunchKernelGGL((classify_kernel<R4>), dim3(cdiv(slots, 256)), dim3(256), 0, e->stream, posk, slots, lo[0], lo[1], lo[2], width,
-                           d->d_split, W, d->split[d->rank], d->split[d->rank + 1], d->d_counts);
+                           d->d_split, W, d->split[d->rank], d->split[d->rank + 1], d->d_counts, d->dest_of);
+        hipLaunchKernelGGL(pack_starts_kernel, dim3(1), dim3(64), 0, e->stream, d->d_counts, W);
+        // the pack pass needs nothing from the host (a workgroup without leavers ends at once), so it is queued before
+        // the counts are waited for
+        NBE_TRY(frame_stream_guard_write(e, e->cur));
+        hipLaunchKernelGGL((pack_kernel<S4>), dim3(cdiv(slots, 256 * PACK_SLOTS)), dim3(256), 0, e->stream, d->dest_of, (S4*)e->posm[e->cur],
+                           (S4*)e->vel[e->cur], e->cfg.precision == NBE_PREC_MIXED ? e->mirror[e->cur] : (float4*)nullptr,
+                           e->orig[e->orig_cur], slots, lo[0], lo[1], lo[2], width, W, d->d_counts, (S4*)d->outbox, d->free_slots,
+                           (const double*)e->radius[e->cur], d->rec_elems);
         NBE_HIP(hipGetLastError());
     }
     NBE_HIP(hipMemcpyAsync(d->h_counts, d->d_counts, (size_t)W * 4, hipMemcpyDeviceToHost, e->stream));
+    // (this wait also covers a caller that reads the outbox on streams the engine knows nothing of)
     NBE_HIP(hipStreamSynchronize(e->stream));
     uint32_t off = 0;
-    for (int r = 0; r < W; r++) { send_counts[r] = d->h_counts[r]; d->h_counts[W + r] = off; off += d->h_counts[r]; }
+    for (int r = 0; r < W; r++) { send_counts[r] = d->h_counts[r]; off += d->h_counts[r]; }
     d->n_free = off;
-    if (off > 0) {
-        NBE_HIP(hipMemcpyAsync(d->d_counts + W, d->h_counts + W, (size_t)W * 4, hipMemcpyHostToDevice, e->stream));
-        NBE_TRY(frame_stream_guard_write(e, e->cur));
-        hipLaunchKernelGGL((pack_kernel<R4, S4>), dim3(cdiv(slots, 256)), dim3(256), 0, e->stream, posk, (S4*)e->posm[e->cur],
-                           (S4*)e->vel[e->cur], e->cfg.precision == NBE_PREC_MIXED ? e->mirror[e->cur] : (float4*)nullptr,
-                           e->orig[e->orig_cur], slots, lo[0], lo[1], lo[2], width, d->d_split, W, d->split[d->rank], d->split[d->rank + 1],
-                           d->d_counts, (S4*)d->outbox, d->free_slots, (const double*)e->radius[e->cur], d->rec_elems);
-        NBE_HIP(hipGetLastError());
-        // a caller that has not given the engine its own stream reads the outbox on streams the engine knows nothing of
-        if (e->stream == e->own_stream) NBE_HIP(hipStreamSynchronize(e->stream));
-    }
+    if ((size_t)off > d->cap) { nbe_set_error("internal: %u leavers of %zu slots", off, d->cap); return NBE_E_INVALID; }
     return NBE_OK;
 }
 
@@ -705,8 +739,7 @@ extern "C" int nbe_dist_build(nbe_engine* e, nbe_fragment_t* frags, int max, int
     if (e->n == 0) {
         NBE_HIP(hipMemsetAsync(e->tw.counters, 0, 16 * sizeof(int), e->stream));
     } else {
-        NBE_TRY(tree_sort_and_build(e));              // (with collisions on it also leaves the search's geometry records)
-        if (!e->cfg.collisions) NBE_TRY(collide_emit_geometry(e));
+        NBE_TRY(tree_sort_and_build(e));              // (also leaves the geometry records of the nodes: key, depth, parent depth)
         hipLaunchKernelGGL(fragments_kernel, dim3(cdiv(2 * e->n, 256)), dim3(256), 0, e->stream, e->cw.cnodes, e->tw.counters,
                            (const Q4*)e->tw.prefixq, d->split[d->rank], d->split[d->rank + 1], d->d_frags, d->d_nfrag, d->d_frag_bodies);
         NBE_TRY(fragment_boxes(e, box_rows));

@@ -242,7 +242,6 @@ int collide_workspace_reserve(nbe_engine* e);
 int collide_workspace_free(nbe_engine* e);
 int collide_fill_radius(nbe_engine* e, double* dst, double value);
 int collide_emit_nodes(nbe_engine* e);          // after the build: geometry records for the collision search
-int collide_emit_geometry(nbe_engine* e);       // key, depth and parent depth of every node only (dist.hip)
 int collide_begin(nbe_engine* e);               // first half of collide_and_update: queues the counting search, does not wait
 int collide_and_update(nbe_engine* e);          // search + merge + update of the state in e->cur into e->cur^1
 // direct_collide.hip

@@ -932,8 +932,11 @@ __global__ __launch_bounds__(256) void emit_nodes_kernel(int n, int* __restrict_
                                                          double bound_width, double theta, double eps2, NodeT* __restrict__ nodes,
                                                          uint8_t* __restrict__ node_level, double* __restrict__ node_sum,
                                                          const D4* __restrict__ prefix, const Q4* __restrict__ prefixq,
-                                                         int shift_m, int shift_x)
+                                                         int shift_m, int shift_x, const uint64_t* __restrict__ keys,
+                                                         const int* __restrict__ bt_parent, CNode* __restrict__ geom)
 {
+    // geom != nullptr (a rank of the distributed tree without collisions): the key, depth and parent depth of every node
+    // are written here too, as emit_cnodes_kernel (collide.hip) would in a pass of its own over the same arrays
     const int na = counters[0];
     // Even workgroups (in the XCD-contiguous numbering) emit 256 leaves, odd ones the cells among the 256 binary nodes of
     // the same index range: the two kinds read the same lines of the cell counts, and every XCD gets its share of both.
@@ -960,6 +963,17 @@ __global__ __launch_bounds__(256) void emit_nodes_kernel(int n, int* __restrict_
         set_edge<NodeT>(nd, 0.0, theta, eps2);
         nd.skip = pos + 1;
         nodes[pos] = nd;
+        if (geom) {
+            CNode c;
+            c.pmask = 0; c.pad0 = 0; c.parent = -1;
+            const uint64_t ki = keys[t];
+            const int dl = key_delta(keys, na, t, ki, t - 1), dr = key_delta(keys, na, t, ki, t + 1);
+            const int d = dl > dr ? dl : dr;
+            c.key = ki; c.body = t; c.skip = pos + 1;
+            if (d < 0) { c.level = 0; c.plevel = 255; }          // a single body: the root is its leaf
+            else { const int pl = delta_level(d); c.plevel = (uint8_t)pl; c.level = (uint8_t)(pl + 1); }
+            geom[pos] = c;
+        }
         if (SUMS == NBE_SUMS_TREE) {
             node_level[pos] = 255;
             const double m = (double)p.w;
@@ -988,6 +1002,15 @@ __global__ __launch_bounds__(256) void emit_nodes_kernel(int n, int* __restrict_
     set_edge<NodeT>(nd, bound_width * (1.0 / (double)(1u << lvl)), theta, eps2);   // edge: exact halving of a power of two
     nd.skip = (b + 1) + (int)cellcnt[b + 1];
     nodes[pos] = nd;
+    if (geom) {
+        CNode c;
+        c.pmask = 0; c.pad0 = 0; c.parent = -1;
+        const int par = bt_parent[i];
+        c.key = keys[a]; c.body = -1; c.skip = nd.skip;
+        c.level = (uint8_t)lvl;
+        c.plevel = par < 0 ? (uint8_t)255 : bt_level[par];
+        geom[pos] = c;
+    }
     if (SUMS == NBE_SUMS_TREE) node_level[pos] = (uint8_t)lvl;
 }
 
@@ -1376,7 +1399,8 @@ static int sort_and_build_t(nbe_engine* e)
     hipLaunchKernelGGL((emit_nodes_kernel<R4, NodeT, SUMS>), dim3(2 * cdiv((size_t)n, 256)), dim3(256), 0, e->stream, n,
                        w.counters, sorted_pos, w.bt_first, w.bt_last, w.bt_cell, w.bt_level, w.lvlmask, w.cellcnt, W,
                        e->cfg.theta, e->cfg.eps * e->cfg.eps, (NodeT*)w.nodes, w.node_level, w.node_sum, (const D4*)w.prefix,
-                       (const Q4*)w.prefixq, w.q_shift_m, w.q_shift_x);
+                       (const Q4*)w.prefixq, w.q_shift_m, w.q_shift_x, w.keys[0], w.bt_parent,
+                       (e->dist && !e->cfg.collisions) ? e->cw.cnodes : (CNode*)nullptr);
     NBE_HIP(hipGetLastError());
     if (SUMS == NBE_SUMS_TREE) {
         for (int level = 21; level >= 0; level--) {
