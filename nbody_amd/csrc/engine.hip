@@ -120,6 +120,10 @@ extern "C" int nbe_create(const nbe_config* cfg, nbe_engine** out)
         const long v = strtol(env, nullptr, 10);
         if (v == 1 || v == 2) e->walk_bodies_per_lane = (int)v;
     }
+    if (const char* env = getenv("NBODY_WALK_XCD_CHUNK_LOG2")) {      // measurement knob: how the walk's workgroups are dealt to the XCDs
+        const long v = strtol(env, nullptr, 10);
+        if (v >= 0 && v <= 12) e->walk_xcd_shift = (int)v;
+    }
     if (const char* env = getenv("NBODY_WALK_PRIVATE")) e->walk_private = env[0] == '1';     // measurement knob, see walk_private_kernel
     int rc = use_device(e);
     if (rc == NBE_OK && hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking) != hipSuccess) {

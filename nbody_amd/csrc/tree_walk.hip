@@ -173,6 +173,24 @@ __device__ __forceinline__ bool node_opens(const RawD& nd, double r2, double the
 #define WALK_BLOCK 256
 #endif
 
+// Which workgroup's bodies this workgroup walks.  Workgroups are dealt round-robin to the 8 XCDs, each with its own 4 MB
+// L2.  xcd_shift = 0: the workgroups of one XCD own one contiguous eighth of the launch's Morton-ordered bodies, so their
+// walks share the same near-field nodes in that L2 instead of every XCD streaming the whole tree (bijective for any grid
+// size).  That is right when the eighths hold alike work, as those of a whole scene do by symmetry; the bodies of one rank
+// of a distributed tree run from the outskirts of an octant to the dense centre, and the XCD with the last eighth would
+// finish long after the others.  xcd_shift = s > 0 deals chunks of 2^s consecutive workgroups to the XCDs in turn instead
+// (the grid is a multiple of 8 * 2^s then; workgroups past the bodies find nothing to do).  Only speed depends on it.
+__device__ __forceinline__ unsigned walk_workgroup(unsigned xcd_shift)
+{
+    const unsigned nwg = gridDim.x, xcd = blockIdx.x % 8, k = blockIdx.x / 8;
+    if (xcd_shift == 0) {
+        const unsigned q8 = nwg / 8, r8 = nwg % 8;
+        return (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + k;
+    }
+    return ((k >> xcd_shift) << (xcd_shift + 3)) + (xcd << xcd_shift) + (k & ((1u << xcd_shift) - 1u));
+}
+
+
 // COUNT: instrumented pass: also counts the force evaluations (tree.go:232-238 executions) of the wave and sums
 // each body's potential (sum of mass / softened distance over the same accepted nodes, returned in the w
 // component of the acceleration record, without the factor -G); the production step runs without it.
@@ -237,7 +255,7 @@ __global__ __launch_bounds__(WALK_BLOCK) void walk_kernel(
     const typename V4<A>::type* __restrict__ pos_in, const typename V4<A>::type* __restrict__ vel_in,
     typename V4<A>::type* __restrict__ pos_out, typename V4<A>::type* __restrict__ vel_out,
     float4* __restrict__ mirror_out, unsigned long long* __restrict__ interactions,
-    const uint32_t* __restrict__ tail_orig, unsigned tail_limit)
+    const uint32_t* __restrict__ tail_orig, unsigned tail_limit, unsigned xcd_shift)
 {
     using R4 = typename V4<R>::type;
     using A4 = typename V4<A>::type;
@@ -245,12 +263,7 @@ __global__ __launch_bounds__(WALK_BLOCK) void walk_kernel(
     const int na = counters[0];
     const int total = counters[1];
     const int tend = t1 < na ? t1 : na;
-    // Workgroups are dealt round-robin to the 8 XCDs, each with its own 4 MB L2.  Remap so that the
-    // workgroups of one XCD own one contiguous eighth of the Morton-ordered bodies: their walks then share
-    // the same near-field nodes in that L2 instead of every XCD streaming the whole tree (bijective for any
-    // grid size; a placement assumption that only affects speed).
-    const unsigned nwg = gridDim.x, q8 = nwg / 8, r8 = nwg % 8, xcd = blockIdx.x % 8;
-    const unsigned wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + blockIdx.x / 8;
+    const unsigned wg = walk_workgroup(xcd_shift);
     const int i = t0 + (int)wg * WALK_BLOCK + threadIdx.x;
     if (OUT == OUT_FUSED) {
         // bodies past n_alive (removed by the bound check) move to the next buffer unchanged
@@ -576,7 +589,8 @@ __global__ __launch_bounds__(WALK_BLOCK) void walk_pair_kernel(
     float floor2, A G, A dt, typename V4<A>::type* __restrict__ acc_out, const typename V4<A>::type* __restrict__ pos_in,
     const typename V4<A>::type* __restrict__ vel_in, typename V4<A>::type* __restrict__ pos_out,
     typename V4<A>::type* __restrict__ vel_out, float4* __restrict__ mirror_out,
-    unsigned long long* __restrict__ interactions, const uint32_t* __restrict__ tail_orig, unsigned tail_limit)
+    unsigned long long* __restrict__ interactions, const uint32_t* __restrict__ tail_orig, unsigned tail_limit,
+    unsigned xcd_shift)
 {
     typedef float R2 __attribute__((ext_vector_type(2)));
     using A4 = typename V4<A>::type;
@@ -584,9 +598,7 @@ __global__ __launch_bounds__(WALK_BLOCK) void walk_pair_kernel(
     const int na = counters[0];
     const int total = counters[1];
     const int tend = t1 < na ? t1 : na;
-    // same XCD-aware placement as walk_kernel: the workgroups of one XCD own a contiguous eighth of the bodies
-    const unsigned nwg = gridDim.x, q8 = nwg / 8, r8 = nwg % 8, xcd = blockIdx.x % 8;
-    const unsigned wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + blockIdx.x / 8;
+    const unsigned wg = walk_workgroup(xcd_shift);     // same XCD-aware placement as walk_kernel
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int idx[2];
     idx[0] = t0 + (int)wg * (2 * WALK_BLOCK) + wave * 128 + lane;
@@ -785,6 +797,13 @@ __global__ __launch_bounds__(WALK_BLOCK) void walk_private_kernel(const NodeF* _
     }
 }
 
+static inline unsigned xcd_grid(unsigned nwg, unsigned xcd_shift)
+{
+    if (xcd_shift == 0) return nwg;
+    const unsigned g = 8u << xcd_shift;
+    return (nwg + g - 1) / g * g;
+}
+
 template <typename R, typename A, typename NodeT>
 static int launch_walk(nbe_engine* e, const void* src, uint64_t t0, uint64_t t1, bool fused, bool count, int src_buf, int dst_buf)
 {
@@ -808,6 +827,12 @@ static int launch_walk(nbe_engine* e, const void* src, uint64_t t0, uint64_t t1,
     float4* mirror_out = mixed ? e->mirror[dst_buf] : nullptr;
     const uint32_t* tail_orig = (e->cfg.reference_quirks & NBE_QUIRK_DROP_TAIL) ? e->orig[e->orig_cur] : nullptr;
     const unsigned tail_limit = (unsigned)(4 * (e->n / 4));
+    // chunks of workgroups dealt to the XCDs in turn, or one contiguous eighth each (walk_workgroup)
+    // (measured: a whole Plummer sphere walks fastest with contiguous eighths, 1M / 2M / 4M / 16M bodies 1.78 / 3.35 / 6.31 /
+    // 25.6 ms against 1.97 / 3.49 / 6.60 / 25.6 with chunks of 64; a rank's 2.1M bodies of a 16M-body tree 3.77 ms against
+    // 3.62 with chunks of 16 to 64; so chunks serve launches that cover a part of a scene: ranks and shards)
+    const bool part = e->dist || nt < (size_t)e->n;
+    const unsigned xcd_shift = e->walk_xcd_shift >= 0 ? (unsigned)e->walk_xcd_shift : (part ? 5u : 0u);
     if (group) {
         dim3 ggrid(cdiv((size_t)(t1 - (t0 & ~127ull)), 2 * WALK_BLOCK));
 #define GROUP_LAUNCH(...)                                                                                    \
@@ -863,11 +888,11 @@ static int launch_walk(nbe_engine* e, const void* src, uint64_t t0, uint64_t t1,
         const size_t least = __is_same(A, float) ? (e->dist ? 3u * (1u << 19) : 2u * (1u << 20)) : (1u << 20);
         const bool pair = (forced == 2 || (forced != 1 && deciding >= least)) && !(count && !__is_same(A, float));
         if (pair) {
-            dim3 pgrid(cdiv(nt, 2 * WALK_BLOCK));
+            dim3 pgrid(xcd_grid(cdiv(nt, 2 * WALK_BLOCK), xcd_shift));
 #define PAIR_LAUNCH(...)                                                                                                       \
     hipLaunchKernelGGL((walk_pair_kernel<A, __VA_ARGS__>), pgrid, dim3(WALK_BLOCK), 0, e->stream, (const NodeF*)e->tw.nodes,   \
                        e->tw.counters, (const float4*)src, (int)t0, (int)t1, floor2, G, dt, (A4*)e->acc, pos_in, vel_in,       \
-                       pos_out, vel_out, mirror_out, e->tw.d_interactions, tail_orig, tail_limit)
+                       pos_out, vel_out, mirror_out, e->tw.d_interactions, tail_orig, tail_limit, xcd_shift)
             if (fused) {
                 PAIR_LAUNCH(OUT_FUSED, false);
             } else if (count) {
@@ -883,20 +908,20 @@ static int launch_walk(nbe_engine* e, const void* src, uint64_t t0, uint64_t t1,
             return NBE_OK;
         }
     }
-    dim3 grid(cdiv(nt, WALK_BLOCK));
+    dim3 grid(xcd_grid(cdiv(nt, WALK_BLOCK), xcd_shift));
     if (fused) {
         WALK_LAUNCH(OUT_FUSED, false) grid, dim3(WALK_BLOCK), 0, e->stream, (const NodeT*)e->tw.nodes,
                            e->tw.counters, (const R4*)src, (int)t0, (int)t1, (R)e->cfg.theta, floor2, G, dt, (A4*)e->acc,
-                           pos_in, vel_in, pos_out, vel_out, mirror_out, e->tw.d_interactions, tail_orig, tail_limit);
+                           pos_in, vel_in, pos_out, vel_out, mirror_out, e->tw.d_interactions, tail_orig, tail_limit, xcd_shift);
     } else if (count) {
         NBE_HIP(hipMemsetAsync(e->tw.d_interactions, 0, 8 * sizeof(unsigned long long), e->stream));
         WALK_LAUNCH(OUT_ACC, true) grid, dim3(WALK_BLOCK), 0, e->stream, (const NodeT*)e->tw.nodes,
                            e->tw.counters, (const R4*)src, (int)t0, (int)t1, (R)e->cfg.theta, floor2, G, dt, (A4*)e->acc,
-                           pos_in, vel_in, pos_out, vel_out, mirror_out, e->tw.d_interactions, tail_orig, tail_limit);
+                           pos_in, vel_in, pos_out, vel_out, mirror_out, e->tw.d_interactions, tail_orig, tail_limit, xcd_shift);
     } else {
         WALK_LAUNCH(OUT_ACC, false) grid, dim3(WALK_BLOCK), 0, e->stream, (const NodeT*)e->tw.nodes,
                            e->tw.counters, (const R4*)src, (int)t0, (int)t1, (R)e->cfg.theta, floor2, G, dt, (A4*)e->acc,
-                           pos_in, vel_in, pos_out, vel_out, mirror_out, e->tw.d_interactions, tail_orig, tail_limit);
+                           pos_in, vel_in, pos_out, vel_out, mirror_out, e->tw.d_interactions, tail_orig, tail_limit, xcd_shift);
     }
     NBE_HIP(hipGetLastError());
     return NBE_OK;
