@@ -63,7 +63,7 @@ struct DistState {
     bool classified = false, built = false, exported = false, assembled = false, have_total = false;
     // fragments of the last build
     nbe_fragment_t* d_frags = nullptr;
-    int* d_nfrag = nullptr;             // [0] count, [1] overflow flag of the export buffer
+    int* d_nfrag = nullptr;             // [0] fragments of the last build, [2..5] a copy of the build's counters (one read-back for both)
     nbe_fragment_t* h_frags = nullptr;  // pinned
     int* h_small = nullptr;             // pinned scratch: counters and sizes
     double* d_aabb = nullptr;           // [MAX_FRAGMENTS][6] boxes of the fragments' bodies, then [MAX_FRAGMENTS][BOX_PARTS][6] partial ones
@@ -76,27 +76,30 @@ struct DistState {
     uint32_t* x_cover = nullptr;
     uint32_t* x_flag = nullptr;
     uint32_t* x_index = nullptr;
-    int* d_seg_first = nullptr;         // per segment: its first work item (assemble_kernel)
-    Segment* h_segments = nullptr;      // pinned copies the layout is staged in, so that the upload needs no wait
-    int* h_seg_first = nullptr;
-    TopCell* h_top = nullptr;
-    int* h_let_counters = nullptr;
     void* export_nodes = nullptr;
     size_t export_cap = 0;
+    void* d_xout = nullptr;             // one block: the three arrays below
+    void* h_xout = nullptr;             // pinned copy
+    size_t xout_bytes = 0;
     unsigned long long* d_export_base = nullptr;   // [0, world] first exported node per destination and the end; then two batch bases
+    int* d_export_overflow = nullptr;   // set when the export buffer is too small
     int* d_export_sizes = nullptr;      // [world][fragments of this rank], room for world x NBE_DIST_MAX_FRAGMENTS
+    void* d_xin = nullptr;              // one block: d_boxes, d_box_counts, d_frags_sorted
+    void* h_xin = nullptr;              // pinned staging of the same
+    size_t xin_bytes = 0;
+    nbe_fragment_t* d_frags_sorted = nullptr;      // this rank's fragments in key order (what the export's kernels read)
     int* d_frag_bodies = nullptr;       // [MAX_FRAGMENTS][2]: first body and one past the last body of every fragment
     double* d_boxes = nullptr;          // world x (MAX_BOXES + 1) x 6: a rank's boxes, then the box around them all
-    std::vector<double> boxes_host;
     int* d_box_counts = nullptr;        // world
     // import + assembled array
     void* import_nodes = nullptr;
     size_t import_cap = 0;
     void* let_nodes = nullptr;
     size_t let_cap = 0;
-    int* let_counters = nullptr;        // [0] live bodies of this rank, [1] nodes of the assembled array
-    Segment* d_segments = nullptr;
-    TopCell* d_top = nullptr;
+    int* let_counters = nullptr;        // [0] live bodies of this rank, [1] nodes of the assembled array: the head of d_ain
+    void* d_ain = nullptr;              // nbe_dist_assemble's input block on the device
+    void* h_ain = nullptr;              // pinned staging of the same
+    size_t ain_bytes = 0;
     size_t seg_cap = 0, top_cap = 0;
 };
 
@@ -120,11 +123,10 @@ void dist_destroy(nbe_engine* e)
     if (!d) return;
     void** dev[] = {(void**)&d->d_split, (void**)&d->d_counts, &d->outbox, &d->inbox, (void**)&d->free_slots, (void**)&d->dest_of, (void**)&d->d_frags,
                     (void**)&d->d_nfrag, (void**)&d->d_aabb, (void**)&d->x_diff, (void**)&d->x_cover, (void**)&d->x_flag,
-                    (void**)&d->x_index, (void**)&d->d_seg_first, &d->export_nodes, (void**)&d->d_export_base, (void**)&d->d_export_sizes,
-                    (void**)&d->d_boxes, (void**)&d->d_frag_bodies, (void**)&d->d_box_counts, &d->import_nodes, &d->let_nodes, (void**)&d->let_counters, (void**)&d->d_segments,
-                    (void**)&d->d_top};
+                    (void**)&d->x_index, &d->export_nodes, &d->d_xout, &d->d_xin,
+                    (void**)&d->d_frag_bodies, &d->import_nodes, &d->let_nodes, &d->d_ain};
     for (void** p : dev) (void)dfree(p);
-    void* host[] = {d->h_counts, d->h_frags, d->h_small, d->h_aabb, d->h_segments, d->h_seg_first, d->h_top, d->h_let_counters};
+    void* host[] = {d->h_counts, d->h_frags, d->h_small, d->h_aabb, d->h_ain, d->h_xout, d->h_xin};
     for (void* p : host)
         if (p) (void)hipHostFree(p);
     delete d;
@@ -207,7 +209,7 @@ extern "C" int nbe_dist_upload(nbe_engine* e, int rank, int world, size_t capaci
     NBE_HIP(hipMalloc((void**)&d->free_slots, capacity * 4));
     NBE_HIP(hipMalloc((void**)&d->dest_of, capacity * sizeof(uint16_t)));
     NBE_HIP(hipMalloc((void**)&d->d_frags, NBE_DIST_MAX_FRAGMENTS * sizeof(nbe_fragment_t)));
-    NBE_HIP(hipMalloc((void**)&d->d_nfrag, 2 * sizeof(int)));
+    NBE_HIP(hipMalloc((void**)&d->d_nfrag, 8 * sizeof(int)));
     NBE_HIP(hipHostMalloc((void**)&d->h_frags, NBE_DIST_MAX_FRAGMENTS * sizeof(nbe_fragment_t), hipHostMallocDefault));
     NBE_HIP(hipHostMalloc((void**)&d->h_small, (16 + (W2 + 1) * 2 + W2 * NBE_DIST_MAX_FRAGMENTS) * sizeof(int), hipHostMallocDefault));
     NBE_HIP(hipMalloc((void**)&d->d_frag_bodies, (size_t)NBE_DIST_MAX_FRAGMENTS * 2 * sizeof(int)));
@@ -229,21 +231,30 @@ extern "C" int nbe_dist_upload(nbe_engine* e, int rank, int world, size_t capaci
     NBE_HIP(hipMalloc(&d->import_nodes, d->import_cap * node_bytes));
     NBE_HIP(hipMalloc(&d->let_nodes, (d->let_cap + 2) * node_bytes));
     NBE_HIP(hipMemsetAsync(d->let_nodes, 0, (d->let_cap + 2) * node_bytes, e->stream));
-    NBE_HIP(hipMalloc((void**)&d->let_counters, 16 * sizeof(int)));
-    NBE_HIP(hipMemsetAsync(d->let_counters, 0, 16 * sizeof(int), e->stream));
-    NBE_HIP(hipMalloc((void**)&d->d_export_base, (W2 + 3) * sizeof(unsigned long long)));
-    NBE_HIP(hipMalloc((void**)&d->d_export_sizes, W2 * NBE_DIST_MAX_FRAGMENTS * sizeof(int)));
-    NBE_HIP(hipMalloc((void**)&d->d_boxes, W2 * (NBE_DIST_MAX_BOXES + 1) * 6 * sizeof(double)));
-    NBE_HIP(hipMalloc((void**)&d->d_box_counts, W2 * sizeof(int)));
+    // The export's small results live in one block (one memset, one copy back): [first node per destination and the end,
+    // two batch bases | overflow flag | sizes of the fragments per destination]; its small inputs in another (one copy
+    // in): [the ranks' boxes | how many of them count | this rank's fragments in key order].
+    d->xout_bytes = (W2 + 3) * sizeof(unsigned long long) + 2 * sizeof(int) + W2 * NBE_DIST_MAX_FRAGMENTS * sizeof(int);
+    NBE_HIP(hipMalloc(&d->d_xout, d->xout_bytes));
+    NBE_HIP(hipHostMalloc(&d->h_xout, d->xout_bytes, hipHostMallocDefault));
+    d->d_export_base = (unsigned long long*)d->d_xout;
+    d->d_export_overflow = (int*)(d->d_export_base + (W2 + 3));
+    d->d_export_sizes = d->d_export_overflow + 2;
+    const size_t boxes_bytes = W2 * (NBE_DIST_MAX_BOXES + 1) * 6 * sizeof(double), counts_bytes = (W2 * sizeof(int) + 7) / 8 * 8;
+    d->xin_bytes = boxes_bytes + counts_bytes + (size_t)NBE_DIST_MAX_FRAGMENTS * sizeof(nbe_fragment_t);
+    NBE_HIP(hipMalloc(&d->d_xin, d->xin_bytes));
+    NBE_HIP(hipHostMalloc(&d->h_xin, d->xin_bytes, hipHostMallocDefault));
+    d->d_boxes = (double*)d->d_xin;
+    d->d_box_counts = (int*)((char*)d->d_xin + boxes_bytes);
+    d->d_frags_sorted = (nbe_fragment_t*)((char*)d->d_xin + boxes_bytes + counts_bytes);
     d->seg_cap = W2 * NBE_DIST_MAX_FRAGMENTS;
     d->top_cap = W2 * NBE_DIST_MAX_FRAGMENTS;
-    NBE_HIP(hipMalloc((void**)&d->d_segments, d->seg_cap * sizeof(Segment)));
-    NBE_HIP(hipMalloc((void**)&d->d_seg_first, d->seg_cap * sizeof(int)));
-    NBE_HIP(hipHostMalloc((void**)&d->h_segments, d->seg_cap * sizeof(Segment), hipHostMallocDefault));
-    NBE_HIP(hipHostMalloc((void**)&d->h_seg_first, d->seg_cap * sizeof(int), hipHostMallocDefault));
-    NBE_HIP(hipHostMalloc((void**)&d->h_top, d->top_cap * sizeof(TopCell), hipHostMallocDefault));
-    NBE_HIP(hipHostMalloc((void**)&d->h_let_counters, 2 * sizeof(int), hipHostMallocDefault));
-    NBE_HIP(hipMalloc((void**)&d->d_top, d->top_cap * sizeof(TopCell)));
+    // what nbe_dist_assemble hands the device, in one block: the walk's two counters, then segments, first work items, cells
+    d->ain_bytes = 64 + d->seg_cap * (sizeof(Segment) + sizeof(int)) + d->top_cap * sizeof(TopCell) + 64;
+    NBE_HIP(hipMalloc(&d->d_ain, d->ain_bytes));
+    NBE_HIP(hipMemsetAsync(d->d_ain, 0, 64, e->stream));
+    NBE_HIP(hipHostMalloc(&d->h_ain, d->ain_bytes, hipHostMallocDefault));
+    d->let_counters = (int*)d->d_ain;
     d->split.assign(W2 + 1, 0);
     d->split[W2] = 1ull << 63;
     for (size_t r = 1; r < W2; r++) d->split[r] = rank == 0 ? (1ull << 63) : 0;   // until splitters are set: rank 0 would own everything
@@ -654,9 +665,11 @@ __global__ __launch_bounds__(256) void box_partial_kernel(const R4* __restrict__
     if (threadIdx.x < 6) part[((size_t)g * BOX_PARTS + blockIdx.x) * 6 + threadIdx.x] = s[threadIdx.x][0];
 }
 
-__global__ __launch_bounds__(256) void box_final_kernel(const double* __restrict__ part, const int* __restrict__ nfrag, double* __restrict__ out)
+__global__ __launch_bounds__(256) void box_final_kernel(const double* __restrict__ part, int* __restrict__ nfrag, double* __restrict__ out,
+                                                        const int* __restrict__ counters)
 {
     const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t < 4) nfrag[2 + t] = counters[t];            // the build's counters ride along with the fragment count
     const int g = t / 6, c = t % 6;
     if (g >= *nfrag || g >= NBE_DIST_MAX_FRAGMENTS) return;
     double v = c < 3 ? INFINITY : -INFINITY;
@@ -716,7 +729,7 @@ static int fragment_boxes(nbe_engine* e, int rows)
     else
         hipLaunchKernelGGL((box_partial_kernel<float4>), dim3(BOX_PARTS, rows), dim3(256), 0, e->stream, (const float4*)key_positions(e),
                            d->d_frag_bodies, d->d_nfrag, part);
-    hipLaunchKernelGGL(box_final_kernel, dim3(cdiv((size_t)rows * 6, 256)), dim3(256), 0, e->stream, part, d->d_nfrag, d->d_aabb);
+    hipLaunchKernelGGL(box_final_kernel, dim3(cdiv((size_t)rows * 6, 256)), dim3(256), 0, e->stream, part, d->d_nfrag, d->d_aabb, e->tw.counters);
     NBE_HIP(hipGetLastError());
     NBE_HIP(hipMemcpyAsync(d->h_aabb, d->d_aabb, (size_t)rows * 6 * sizeof(double), hipMemcpyDeviceToHost, e->stream));
     return NBE_OK;
@@ -735,7 +748,7 @@ extern "C" int nbe_dist_build(nbe_engine* e, nbe_fragment_t* frags, int max, int
     // the box kernel's grid has a row per fragment; their number is known only after the read-back, so the grid is sized
     // from the last build's (fragments come and go a few at a time) and the rare build that outgrows it runs it again
     const int box_rows = std::min(NBE_DIST_MAX_FRAGMENTS, 2 * d->frag_hint + 64);
-    NBE_HIP(hipMemsetAsync(d->d_nfrag, 0, 2 * sizeof(int), e->stream));
+    NBE_HIP(hipMemsetAsync(d->d_nfrag, 0, 8 * sizeof(int), e->stream));
     if (e->n == 0) {
         NBE_HIP(hipMemsetAsync(e->tw.counters, 0, 16 * sizeof(int), e->stream));
     } else {
@@ -745,15 +758,17 @@ extern "C" int nbe_dist_build(nbe_engine* e, nbe_fragment_t* frags, int max, int
         NBE_TRY(fragment_boxes(e, box_rows));
     }
     NBE_HIP(hipGetLastError());
-    NBE_HIP(hipMemcpyAsync(d->h_small, e->tw.counters, 4 * sizeof(int), hipMemcpyDeviceToHost, e->stream));
-    NBE_HIP(hipMemcpyAsync(d->h_small + 4, d->d_nfrag, sizeof(int), hipMemcpyDeviceToHost, e->stream));
-    NBE_HIP(hipMemcpyAsync(d->h_frags, d->d_frags, NBE_DIST_MAX_FRAGMENTS * sizeof(nbe_fragment_t), hipMemcpyDeviceToHost, e->stream));
+    NBE_HIP(hipMemcpyAsync(d->h_small, d->d_nfrag, 8 * sizeof(int), hipMemcpyDeviceToHost, e->stream));
+    // (as many fragments as the box kernel's grid has rows; the rare build with more fetches the rest below)
+    NBE_HIP(hipMemcpyAsync(d->h_frags, d->d_frags, (size_t)box_rows * sizeof(nbe_fragment_t), hipMemcpyDeviceToHost, e->stream));
     NBE_HIP(hipStreamSynchronize(e->stream));
-    const int na = d->h_small[0], nf = d->h_small[4];
+    const int nf = d->h_small[0];
+    const int na = d->h_small[2];
     if (nf > NBE_DIST_MAX_FRAGMENTS || nf > max) { nbe_set_error("rank %d has %d fragments (limit %d)", d->rank, nf, std::min(max, NBE_DIST_MAX_FRAGMENTS)); return NBE_E_UNSUPPORTED; }
     d->frag_hint = nf;
     if (nf > box_rows) {
         NBE_TRY(fragment_boxes(e, nf));
+        NBE_HIP(hipMemcpyAsync(d->h_frags, d->d_frags, (size_t)nf * sizeof(nbe_fragment_t), hipMemcpyDeviceToHost, e->stream));
         NBE_HIP(hipStreamSynchronize(e->stream));
     }
     d->my_frags.assign(d->h_frags, d->h_frags + nf);
@@ -779,8 +794,8 @@ extern "C" int nbe_dist_build(nbe_engine* e, nbe_fragment_t* frags, int max, int
     d->built = true; d->classified = false; d->exported = false; d->assembled = false;
     e->prepared = true;
     e->stats.n_alive = (uint64_t)na;
-    e->stats.tree_nodes = (uint64_t)d->h_small[1];
-    e->stats.tree_cells = (uint64_t)d->h_small[2];
+    e->stats.tree_nodes = (uint64_t)d->h_small[3];
+    e->stats.tree_cells = (uint64_t)d->h_small[4];
     e->host_nalive = (size_t)na;
     return NBE_OK;
 }
@@ -985,10 +1000,9 @@ static int export_t(nbe_engine* e, int32_t* export_sizes, uint64_t* export_offse
     uint32_t* blockcnt = d->x_flag + (L + 3) / 4 + 1;              // [8][nblk] + 1
     uint32_t* blockoff = blockcnt + (size_t)EXPORT_BATCH * nblk + 2;
     unsigned long long* batch_base = d->d_export_base + (W + 1);      // two device scalars used in turn
-    NBE_HIP(hipMemsetAsync(d->d_export_base, 0, (size_t)(W + 3) * sizeof(unsigned long long), e->stream));
-    NBE_HIP(hipMemsetAsync(d->d_nfrag + 1, 0, sizeof(int), e->stream));
-    NBE_HIP(hipMemsetAsync(d->d_export_sizes, 0, (size_t)W * (size_t)std::max(nf, 1) * sizeof(int), e->stream));
-    if (nf) NBE_HIP(hipMemcpyAsync(d->d_frags, d->my_frags.data(), (size_t)nf * sizeof(nbe_fragment_t), hipMemcpyHostToDevice, e->stream));
+    // (bases, overflow flag and sizes: one block, cleared at once; the sorted fragments came in with the boxes)
+    const size_t out_bytes = (size_t)(W + 3) * sizeof(unsigned long long) + 2 * sizeof(int) + (size_t)W * (size_t)std::max(nf, 1) * sizeof(int);
+    NBE_HIP(hipMemsetAsync(d->d_xout, 0, out_bytes, e->stream));
     std::vector<int> others;
     for (int q = 0; q < W; q++)
         if (q != d->rank) others.push_back(q);
@@ -1006,22 +1020,20 @@ static int export_t(nbe_engine* e, int32_t* export_sizes, uint64_t* export_offse
         hipLaunchKernelGGL(export_count_kernel, dim3(nblk), dim3(256), 0, e->stream, e->cw.cnodes, e->tw.counters, lo, hi, cover, L, dl.n,
                            inc, rank8, blockcnt, nblk);
         NBE_TRY(device_scan_u32(e, blockcnt, blockoff, (size_t)EXPORT_BATCH * nblk + 1));
-        hipLaunchKernelGGL(export_sizes_kernel, dim3(cdiv(nf, 256), dl.n), dim3(256), 0, e->stream, blockoff, rank8, nblk, d->d_frags, nf, dl,
-                           d->d_export_base, W, cur_base, nxt_base, (unsigned long long)d->export_cap, d->d_export_sizes, d->d_nfrag + 1);
+        hipLaunchKernelGGL(export_sizes_kernel, dim3(cdiv(nf, 256), dl.n), dim3(256), 0, e->stream, blockoff, rank8, nblk, d->d_frags_sorted, nf, dl,
+                           d->d_export_base, W, cur_base, nxt_base, (unsigned long long)d->export_cap, d->d_export_sizes, d->d_export_overflow);
         hipLaunchKernelGGL((export_write_kernel<NodeT>), dim3(cdiv(2 * n, 256)), dim3(256), 0, e->stream, (const NodeT*)e->tw.nodes,
                            e->tw.counters, inc, rank8, blockoff, nblk, dl.n, cur_base, nxt_base, (unsigned long long)d->export_cap,
                            (NodeT*)d->export_nodes);
         NBE_HIP(hipGetLastError());
     }
-    // read back: offsets, overflow flag, sizes
-    unsigned long long* h_base = (unsigned long long*)(d->h_small + 16);
-    int* h_sizes = d->h_small + 16 + 2 * (W + 1);
-    NBE_HIP(hipMemcpyAsync(h_base, d->d_export_base, (size_t)(W + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost, e->stream));
-    NBE_HIP(hipMemcpyAsync(d->h_small, d->d_nfrag, 2 * sizeof(int), hipMemcpyDeviceToHost, e->stream));
-    if (nf)      // (the kernel packs them [destination][fragment] without gaps, so one copy fetches all)
-        NBE_HIP(hipMemcpyAsync(h_sizes, d->d_export_sizes, (size_t)W * nf * sizeof(int), hipMemcpyDeviceToHost, e->stream));
+    // read back: offsets, overflow flag, sizes (one copy; the kernel packs the sizes [destination][fragment] without gaps)
+    NBE_HIP(hipMemcpyAsync(d->h_xout, d->d_xout, out_bytes, hipMemcpyDeviceToHost, e->stream));
     NBE_HIP(hipStreamSynchronize(e->stream));
-    if (d->h_small[1]) { nbe_set_error("rank %d: the export buffer (%zu nodes) is too small", d->rank, d->export_cap); return NBE_E_NOMEM; }
+    const unsigned long long* h_base = (const unsigned long long*)d->h_xout;
+    const int* h_over = (const int*)(h_base + (W + 3));
+    const int* h_sizes = h_over + 2;
+    if (h_over[0]) { nbe_set_error("rank %d: the export buffer (%zu nodes) is too small", d->rank, d->export_cap); return NBE_E_NOMEM; }
     // destinations were written in rank order; a rank that gets nothing (this one) starts where the next one starts
     export_offsets[W] = (uint64_t)h_base[W];
     for (int q = W - 1; q >= 0; q--) export_offsets[q] = (q == d->rank || nf == 0) ? export_offsets[q + 1] : (uint64_t)h_base[q];
@@ -1048,10 +1060,15 @@ extern "C" int nbe_dist_export(nbe_engine* e, const nbe_fragment_t* all_frags, c
     if (total > 0 && !all_frags) { nbe_set_error("all_frags is NULL"); return NBE_E_INVALID; }
     d->all_frags.assign(all_frags, all_frags + total);
     d->frag_counts.assign(frag_counts, frag_counts + d->world);
-    d->boxes_host.assign((size_t)d->world * (NBE_DIST_MAX_BOXES + 1) * 6, 0.0);
+    // boxes, box counts and this rank's fragments (key order) go to the device in one copy from pinned staging
+    // (the previous export's copy was waited for before that call returned)
+    const size_t boxes_bytes = (size_t)d->world * (NBE_DIST_MAX_BOXES + 1) * 6 * sizeof(double);
+    const size_t counts_bytes = ((size_t)d->world * sizeof(int) + 7) / 8 * 8;
+    double* hb = (double*)d->h_xin;
+    memset(hb, 0, boxes_bytes);
     for (int r = 0; r < d->world; r++) {
         const double* src = boxes + (size_t)r * NBE_DIST_MAX_BOXES * 6;
-        double* dst = d->boxes_host.data() + (size_t)r * (NBE_DIST_MAX_BOXES + 1) * 6;
+        double* dst = hb + (size_t)r * (NBE_DIST_MAX_BOXES + 1) * 6;
         double* all = dst + (size_t)NBE_DIST_MAX_BOXES * 6;
         for (int c = 0; c < 3; c++) { all[c] = INFINITY; all[3 + c] = -INFINITY; }
         for (int b = 0; b < box_counts[r]; b++)
@@ -1062,8 +1079,10 @@ extern "C" int nbe_dist_export(nbe_engine* e, const nbe_fragment_t* all_frags, c
                 all[3 + c] = fmax(all[3 + c], src[6 * b + 3 + c]);
             }
     }
-    NBE_HIP(hipMemcpyAsync(d->d_boxes, d->boxes_host.data(), d->boxes_host.size() * sizeof(double), hipMemcpyHostToDevice, e->stream));
-    NBE_HIP(hipMemcpyAsync(d->d_box_counts, box_counts, (size_t)d->world * sizeof(int), hipMemcpyHostToDevice, e->stream));
+    memcpy((char*)d->h_xin + boxes_bytes, box_counts, (size_t)d->world * sizeof(int));
+    const size_t nf = d->my_frags.size();
+    if (nf) memcpy((char*)d->h_xin + boxes_bytes + counts_bytes, d->my_frags.data(), nf * sizeof(nbe_fragment_t));
+    NBE_HIP(hipMemcpyAsync(d->d_xin, d->h_xin, boxes_bytes + counts_bytes + nf * sizeof(nbe_fragment_t), hipMemcpyHostToDevice, e->stream));
     int rc = e->force64 ? export_t<NodeD>(e, export_sizes, export_offsets) : export_t<NodeF>(e, export_sizes, export_offsets);
     if (rc == NBE_OK) d->exported = true;
     return rc;
@@ -1221,39 +1240,45 @@ extern "C" int nbe_dist_assemble(nbe_engine* e, const int32_t* import_sizes, con
     if (!fr.empty()) lay.total = layout_range(fr, 0, (int)fr.size(), 0, seg_of, &lay, &sum);
     if ((size_t)lay.total > d->let_cap) { nbe_set_error("rank %d: the assembled tree (%d nodes) exceeds the buffer (%zu)", d->rank, lay.total, d->let_cap); return NBE_E_NOMEM; }
     if (lay.segs.size() > d->seg_cap || lay.tops.size() > d->top_cap) { nbe_set_error("too many fragments"); return NBE_E_UNSUPPORTED; }
-    // work items: the nodes of all segments, numbered segment after segment
-    // (the pinned staging copies of the previous step were consumed long ago: every step waits for the device several times)
+    // work items: the nodes of all segments, numbered segment after segment.  The two counters the walk reads, the
+    // segments, their first work items and the spanning cells are packed into one pinned block and go up in one copy
+    // (the previous step's copy was consumed long ago: every step waits for the device several times).
+    const size_t nseg = lay.segs.size(), ntop = lay.tops.size();
+    const size_t off_first = 64, off_segs = off_first + (nseg * sizeof(int) + 15) / 16 * 16;
+    const size_t off_tops = off_segs + (nseg * sizeof(Segment) + 15) / 16 * 16;
+    const size_t in_bytes = off_tops + ntop * sizeof(TopCell);
+    if (in_bytes > d->ain_bytes) { nbe_set_error("internal: layout block too small"); return NBE_E_INVALID; }
+    char* hin = (char*)d->h_ain;
+    int* h_first = (int*)(hin + off_first);
+    Segment* h_segs = (Segment*)(hin + off_segs);
+    TopCell* h_tops = (TopCell*)(hin + off_tops);
     long long work = 0;
-    for (size_t s = 0; s < lay.segs.size(); s++) { d->h_seg_first[s] = (int)work; d->h_segments[s] = lay.segs[s]; work += lay.segs[s].count; }
-    for (size_t t = 0; t < lay.tops.size(); t++) d->h_top[t] = lay.tops[t];
-    int* d_seg_first = d->d_seg_first;
-    if (!lay.segs.empty()) {
-        NBE_HIP(hipMemcpyAsync(d->d_segments, d->h_segments, lay.segs.size() * sizeof(Segment), hipMemcpyHostToDevice, e->stream));
-        NBE_HIP(hipMemcpyAsync(d_seg_first, d->h_seg_first, lay.segs.size() * sizeof(int), hipMemcpyHostToDevice, e->stream));
-    }
-    if (!lay.tops.empty())
-        NBE_HIP(hipMemcpyAsync(d->d_top, d->h_top, lay.tops.size() * sizeof(TopCell), hipMemcpyHostToDevice, e->stream));
+    for (size_t k = 0; k < nseg; k++) { h_first[k] = (int)work; h_segs[k] = lay.segs[k]; work += lay.segs[k].count; }
+    for (size_t t = 0; t < ntop; t++) h_tops[t] = lay.tops[t];
+    ((int*)hin)[0] = (int)d->live_hi;
+    ((int*)hin)[1] = lay.total;
+    NBE_HIP(hipMemcpyAsync(d->d_ain, d->h_ain, in_bytes, hipMemcpyHostToDevice, e->stream));
+    const int* d_seg_first = (const int*)((char*)d->d_ain + off_first);
+    const Segment* d_segments = (const Segment*)((char*)d->d_ain + off_segs);
+    const TopCell* d_top = (const TopCell*)((char*)d->d_ain + off_tops);
     const double eps2 = e->cfg.eps * e->cfg.eps;
     const int ntops = (int)lay.tops.size();
     if (e->force64) {
-        hipLaunchKernelGGL((top_cells_kernel<NodeD>), dim3(cdiv(ntops + 1, 256)), dim3(256), 0, e->stream, d->d_top, ntops, e->cfg.bound_width,
+        hipLaunchKernelGGL((top_cells_kernel<NodeD>), dim3(cdiv(ntops + 1, 256)), dim3(256), 0, e->stream, d_top, ntops, e->cfg.bound_width,
                            e->cfg.theta, eps2, lay.total, e->tw.q_shift_m, e->tw.q_shift_x, (NodeD*)d->let_nodes);
         if (work > 0)
-            hipLaunchKernelGGL((assemble_kernel<NodeD>), dim3(cdiv((size_t)work, 256)), dim3(256), 0, e->stream, d->d_segments,
+            hipLaunchKernelGGL((assemble_kernel<NodeD>), dim3(cdiv((size_t)work, 256)), dim3(256), 0, e->stream, d_segments,
                                (int)lay.segs.size(), d_seg_first, (const NodeD*)e->tw.nodes, (const NodeD*)d->import_nodes, work,
                                (NodeD*)d->let_nodes);
     } else {
-        hipLaunchKernelGGL((top_cells_kernel<NodeF>), dim3(cdiv(ntops + 1, 256)), dim3(256), 0, e->stream, d->d_top, ntops, e->cfg.bound_width,
+        hipLaunchKernelGGL((top_cells_kernel<NodeF>), dim3(cdiv(ntops + 1, 256)), dim3(256), 0, e->stream, d_top, ntops, e->cfg.bound_width,
                            e->cfg.theta, eps2, lay.total, e->tw.q_shift_m, e->tw.q_shift_x, (NodeF*)d->let_nodes);
         if (work > 0)
-            hipLaunchKernelGGL((assemble_kernel<NodeF>), dim3(cdiv((size_t)work, 256)), dim3(256), 0, e->stream, d->d_segments,
+            hipLaunchKernelGGL((assemble_kernel<NodeF>), dim3(cdiv((size_t)work, 256)), dim3(256), 0, e->stream, d_segments,
                                (int)lay.segs.size(), d_seg_first, (const NodeF*)e->tw.nodes, (const NodeF*)d->import_nodes, work,
                                (NodeF*)d->let_nodes);
     }
     NBE_HIP(hipGetLastError());
-    d->h_let_counters[0] = (int)d->live_hi;
-    d->h_let_counters[1] = lay.total;
-    NBE_HIP(hipMemcpyAsync(d->let_counters, d->h_let_counters, 2 * sizeof(int), hipMemcpyHostToDevice, e->stream));
     d->assembled = true;
     e->stats.tree_nodes = (uint64_t)lay.total;
     return NBE_OK;
