@@ -137,7 +137,8 @@ def eight_ranks_on_one_gpu(b, one_gpu_ms, **engine_kw):
         timed_s = timed_steps(lambda: tree.step(1), torch.cuda.synchronize, lambda: None, 1, 10)
         timed_ms = 1e3 * timed_s / 10 / nr
         runs = [tree.step_profiled() for _ in range(5)]
-        acc = {k: float(np.median([t[k] for t in runs])) for k in runs[0]}
+        keys = sorted({k for t in runs for k in t})      # (a run in which new splitters were chosen has a phase of its own)
+        acc = {k: float(np.median([t.get(k, 0.0) for t in runs])) for k in keys}
         per_rank = {k: v / nr for k, v in acc.items()}
         return {"timed_ms_per_step_per_rank": timed_ms, "ratio_one_gpu_step_to_timed_rank_step": one_gpu_ms / timed_ms,
                 "timed": "10 steps of all eight ranks end to end without drains, divided by 8",
@@ -545,7 +546,10 @@ def main():
             tree.distribute()
             sec = timed_steps(lambda: tree.step(1), sync, barrier, 2, 5)      # (the first step moves every body to its owner)
             runs = [tree.step_profiled() for _ in range(5)]
-            acc = {k: float(np.median([t[k] for t in runs])) for k in runs[0]}
+            # (a fixed list of phases, alike on every rank: the reduction below goes by position; "rebalance" only shows in
+            # a run in which new splitters were chosen)
+            keys = ["classify", "migrate", "sort_build", "export", "exchange_assemble", "walk", "rebalance"]
+            acc = {k: float(np.median([t.get(k, 0.0) for t in runs])) for k in keys}
             live = float(ranks[0].engine.stats().n_alive)
             if world > 1:
                 t = torch.tensor([sec] + [acc[k] for k in sorted(acc)], device="cuda", dtype=torch.float64)

@@ -50,7 +50,8 @@ tree.step(steps)
 torch.cuda.synchronize()
 timed = (time.perf_counter() - t0) * 1e3 / steps
 runs = [tree.step_profiled() for _ in range(5)]
-acc = {k: float(np.median([t[k] for t in runs])) / world for k in runs[0]}
+keys = sorted({k for t in runs for k in t})      # (a run in which new splitters were chosen has a phase of its own)
+acc = {k: float(np.median([t.get(k, 0.0) for t in runs])) / world for k in keys}
 print(f"{scene} 2^{log2n} bodies world {world} lanes {os.environ.get('NBODY_WALK_BODIES_PER_LANE', 'auto')}: timed step per rank "
       f"{timed / world:.3f} ms (all ranks {timed:.2f}); phase sums per rank {sum(acc.values()):.3f}:",
       {k: round(v, 3) for k, v in acc.items()}, flush=True)
