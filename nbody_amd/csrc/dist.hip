@@ -41,7 +41,7 @@ struct TopCell {          // a cell that spans ranks
     Q4 sum;               // exact sums of its bodies (tree_sums.h)
 };
 
-#define BOX_PARTS 128     // workgroups that share the bodies of one fragment
+#define BOX_PARTS 128     // workgroups that share the bodies of one fragment (32: the few large fragments then take 0.07 ms longer)
 #define EXPORT_BATCH 8    // destinations whose exports are made by the same launches
 #define DIST_MAX_WORLD 1024   // ranks (per-destination counters of a workgroup live in LDS)
 
