@@ -434,6 +434,11 @@ static int collide_begin_t(nbe_engine* e, const void* force_pos)
     const double W = e->cfg.bound_width;
     const double lox = e->cfg.bound_center[0] - 0.5 * W, loy = e->cfg.bound_center[1] - 0.5 * W,
                  loz = e->cfg.bound_center[2] - 0.5 * W;
+    if (n == 0) {                                     // (a rank of the distributed tree may hold no body at all)
+        for (int k = 0; k < 4; k++) w.total_host[k] = 0;
+        w.begun = true;
+        return NBE_OK;
+    }
     NBE_HIP(hipMemsetAsync(w.count, 0, ((size_t)n + 1) * 4, e->stream));
     const RankQueue rq = rank_queue(e);
     if (rq.list) NBE_HIP(hipMemsetAsync(rq.meta, 0, 4 * sizeof(uint32_t), e->stream));
@@ -482,6 +487,7 @@ static int collide_and_update_t(nbe_engine* e, const void* force_pos)
 
     NBE_TRY(collide_begin(e));
     w.begun = false;
+    if (n == 0) { e->stats.collision_pairs = 0; return NBE_OK; }
     NBE_HIP(hipStreamSynchronize(e->stream));
     const RankQueue rq = rank_queue(e);
     const uint32_t total = w.total_host[1];

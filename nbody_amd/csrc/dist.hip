@@ -750,7 +750,9 @@ extern "C" int nbe_dist_build(nbe_engine* e, nbe_fragment_t* frags, int max, int
     const int box_rows = std::min(NBE_DIST_MAX_FRAGMENTS, 2 * d->frag_hint + 64);
     NBE_HIP(hipMemsetAsync(d->d_nfrag, 0, 8 * sizeof(int), e->stream));
     if (e->n == 0) {
-        NBE_HIP(hipMemsetAsync(e->tw.counters, 0, 16 * sizeof(int), e->stream));
+        // no body here: an empty tree (the count of bodies absorbed since the upload, further up in the counters, stays)
+        NBE_HIP(hipMemsetAsync(e->tw.counters, 0, 4 * sizeof(int), e->stream));
+        NBE_HIP(hipMemsetAsync(e->tw.counters + COUNTER_SORTED_ALIVE, 0, sizeof(int), e->stream));
     } else {
         NBE_TRY(tree_sort_and_build(e));              // (also leaves the geometry records of the nodes: key, depth, parent depth)
         hipLaunchKernelGGL(fragments_kernel, dim3(cdiv(2 * e->n, 256)), dim3(256), 0, e->stream, e->cw.cnodes, e->tw.counters,

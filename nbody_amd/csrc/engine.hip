@@ -300,7 +300,8 @@ static int read_counts(nbe_engine* e, size_t* slots)
     size_t* n_alive = slots;
     size_t absorbed = 0;
     *n_alive = e->n;
-    if (e->have_counts && e->n > 0) {
+    // (a rank of the distributed tree that holds no body at the moment still has its count of absorbed bodies)
+    if (e->have_counts && (e->n > 0 || e->dist)) {
         int c[8];
         NBE_HIP(hipMemcpyAsync(c, e->tw.counters, sizeof(c), hipMemcpyDeviceToHost, e->stream));
         NBE_HIP(hipStreamSynchronize(e->stream));

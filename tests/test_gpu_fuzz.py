@@ -134,3 +134,41 @@ def test_random_scenes_on_the_distributed_tree_equal_one_engine(gpu, block):
                 assert np.abs(out[0][0] - out[1][0]).max() <= 1e-9 * (np.abs(out[0][0]).max() + 1e-30), tag
         else:
             assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1]), tag
+
+
+@pytest.mark.parametrize("block", range(2))
+def test_random_scenes_with_collisions_on_the_distributed_tree_equal_one_engine(gpu, block):
+    """The same random scenes with collisions on (radii 0.5 to 40 m, so the splitters are aligned to 4096 m cells):
+    2..6 shards behind one handle against one engine, fp32 and fp64, bit for bit: survivors, masses, states, merges.
+    (NBODY_FUZZ_SEEDS=k runs k scenes per block instead of ten.)"""
+    import os
+    per = int(os.environ.get("NBODY_FUZZ_SEEDS", "10"))
+    merges = 0
+    for s in range(9700 + per * block, 9700 + per * (block + 1)):
+        rng = np.random.default_rng(s)
+        kind, pos, vel, mass, rad = scene(rng)
+        n = len(mass)
+        if kind == "clustered":
+            rad = rad * 0.1                     # (clusters a metre wide would merge into one body at once)
+        elif kind in ("uniform", "mixed") and n > 1:
+            pos = pos * (60.0 * n ** (1 / 3) / 6e4)     # a spacing of a few radii, so that bodies do meet
+        elif kind == "line" and n > 1:
+            pos = pos * (60.0 * n / 6e4)
+        precision = str(rng.choice(["f32", "f64"]))
+        shards = int(rng.integers(2, 7)); nsteps = int(rng.choice([1, 3, 6]))
+        theta = float(rng.choice([0.3, 0.6, 1.0]))
+        tag = f"seed {s}: {kind} n={n} {precision} shards={shards} steps={nsteps} theta={theta}"
+        out = []
+        for kw in (dict(exact_sums=True), dict(devices=[0] * shards, distributed=True)):
+            with Engine(mode="tree", precision=precision, theta=theta, dt=200.0, collisions=True, **kw) as e:
+                e.upload(pos, vel, mass)
+                if n:
+                    e.set_radius(rad)
+                e.step(nsteps)
+                st = e.stats()
+                out.append(e.download() + (int(st.n_alive), int(st.merges)))
+        assert out[0][4:] == out[1][4:], tag
+        for a, b in zip(out[0][:4], out[1][:4]):
+            assert np.array_equal(a, b), tag
+        merges += out[0][5]
+    assert merges > 20, merges                  # the scenes of a block do collide
