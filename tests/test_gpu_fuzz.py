@@ -112,8 +112,11 @@ def test_random_scenes_on_several_shards_equal_one_shard(gpu, block):
 def test_random_scenes_on_the_distributed_tree_equal_one_engine(gpu, block):
     """The key-range-distributed tree behind one handle (2..6 shards on this GPU, every body on one shard only) on the
     same random scenes, bodies on cell boundaries, outside the bound and NaN included: fp32 and fp64 bit for bit against
-    one engine that sums its cells child by child, mixed precision to rounding."""
-    for s in range(9500 + 10 * block, 9500 + 10 * (block + 1)):
+    one engine that sums its cells the same way (exactly), mixed precision to rounding.
+    (NBODY_FUZZ_SEEDS=k runs k scenes per block instead of ten.)"""
+    import os
+    per = int(os.environ.get("NBODY_FUZZ_SEEDS", "10"))
+    for s in range(9500 + per * block, 9500 + per * (block + 1)):
         rng = np.random.default_rng(s)
         kind, pos, vel, mass, rad = scene(rng)
         n = len(mass)
