@@ -109,8 +109,18 @@ def main():
         prec = sys.argv[6]
         per = (n + world - 1) // world
         a, z = min(n, rank * per), min(n, (rank + 1) * per)
-        r = DistRank(rank, world, precision=prec, theta=0.5)
-        r.upload(int(per * 1.5) + 1024, bodies.pos[a:z], bodies.vel[a:z], bodies.mass[a:z], a)
+        extra = {}
+        rad = None
+        if "collide" in sys.argv[7:]:
+            # a crowd that merges: the same generator calls in every process, so every rank sees the same scene
+            rng = np.random.default_rng(5)
+            bodies = physics.Bodies(rng.uniform(-150.0, 150.0, (n, 3)), rng.normal(0, 1e-3, (n, 3)), np.abs(rng.normal(1e3, 500, n)) + 1)
+            rad = np.random.default_rng(6).uniform(0.5, 3.0, n)
+            extra = dict(collisions=True, dt=50.0)
+        r = DistRank(rank, world, precision=prec, theta=0.5, **extra)
+        r.upload(int(per * 2.5) + 1024, bodies.pos[a:z], bodies.vel[a:z], bodies.mass[a:z], a)
+        if rad is not None:
+            r.set_radius(rad[a:z], 8.0)
         r.use_torch_stream()
         dt = DistributedTree([r], TorchComm())
         dt.distribute()

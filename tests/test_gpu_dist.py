@@ -191,6 +191,26 @@ def test_one_process_per_rank_over_torch_distributed(gpu, tmp_path, world, preci
         assert np.array_equal(np.concatenate([r[name] for r in res])[order], w), name
 
 
+def test_one_process_per_rank_with_collisions(gpu, tmp_path):
+    """Collisions on, one rank per process (gloo, all on cuda:0): the survivors and their states equal one engine's."""
+    from tests.test_sharded_gloo import run_ranks
+    n, nsteps = 6000, 12
+    res = run_ranks(tmp_path, 3, ["tree", str(n), str(nsteps), "dist", "f64", "collide"], timeout=240)
+    rng = np.random.default_rng(5)
+    pos, vel, mass = rng.uniform(-150.0, 150.0, (n, 3)), rng.normal(0, 1e-3, (n, 3)), np.abs(rng.normal(1e3, 500, n)) + 1
+    rad = np.random.default_rng(6).uniform(0.5, 3.0, n)
+    with Engine(mode="tree", precision="f64", theta=0.5, dt=50.0, collisions=True, exact_sums=True) as e:
+        e.upload(pos, vel, mass); e.set_radius(rad)
+        e.step(nsteps)
+        wp, wv, wm, wid = e.download()
+        merges = e.stats().merges
+    assert merges > 50
+    idx = np.concatenate([r["ids"] for r in res]); order = np.argsort(idx)
+    assert np.array_equal(idx[order], wid)
+    for key, want in (("pos", wp), ("vel", wv), ("mass", wm)):
+        assert np.array_equal(np.concatenate([r[key] for r in res])[order], want)
+
+
 def test_new_splitters_during_a_run_change_nothing_but_the_owners(gpu):
     """Splitters are chosen anew whenever a rank holds too many bodies (forced here before every step): bodies change
     owner wholesale, the trajectories stay those of one engine."""
