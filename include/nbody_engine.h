@@ -73,7 +73,8 @@ typedef struct {
  * With cfg.distributed = 1 (tree mode, per-body criterion, no reference_quirks; collisions allowed) the GPUs do not replicate the
  * bodies: the engine runs the key-range-distributed tree described at nbe_dist_upload below on its GPUs, one host thread per
  * GPU, with peer copies for the exchanges.  nbe_upload, nbe_step, nbe_download, nbe_stats, nbe_energy (tree potential),
- * nbe_sync and the frame stream work (no GPU holds all bodies: every GPU snapshots its own before the step and sends
+ * nbe_set_radius (right after nbe_upload), nbe_get_radius, nbe_sync and the frame stream, radii included, work (no GPU
+ * holds all bodies: every GPU snapshots its own before the step and sends
  * them into its stretch of the frame's pinned buffer on a stream of its own; the rows of a frame are in key order);
  * results equal those of one GPU with cell_sums = NBE_SUMS_EXACT bit for bit in fp32 and fp64; the other calls are refused. */
 
@@ -189,7 +190,8 @@ int nbe_stats(nbe_engine *e, nbe_stats_t *stats);
 
 /* Total kinetic energy, potential energy (softened by eps) and linear momentum of the live bodies; used for
  * drift checks.  Up to 262,144 bodies the potential is the exact fp64 pair sum; above that, tree mode sums it over
- * the nodes its walk accepts (same theta as the forces) and direct mode accepts up to 4,194,304 bodies.
+ * the nodes its walk accepts (same theta as the forces) and direct mode accepts up to 4,194,304 bodies.  In tree mode
+ * "live" means inside the bound, as the coming step will see them (the call builds the tree, which that step reuses).
  * No counterpart in the reference (its only validation is the rendered frames). */
 int nbe_energy(nbe_engine *e, double *kinetic, double *potential, double momentum[3]);
 
@@ -328,6 +330,9 @@ int nbe_dist_advance(nbe_engine *e);
 int nbe_dist_energy(nbe_engine *e, double *kinetic, double *potential, double momentum[3]);
 /* The rank's live bodies: run-wide index, position, velocity, mass (any pointer may be NULL). */
 int nbe_dist_download(nbe_engine *e, uint64_t *index, double *pos_xyz, double *vel_xyz, double *mass, size_t *count);
+/* Collisions on: the radii of the rank's live bodies (physics.go:94; merged bodies have grown, physics.go:139) with their
+ * run-wide indices, in the order of nbe_dist_download (index may be NULL). */
+int nbe_dist_get_radius(nbe_engine *e, uint64_t *index, double *radius, size_t *count);
 
 /* Run the engine's work on a caller-owned hipStream_t instead of the engine's own non-blocking stream, so
  * that it is ordered with the caller's other work (copies, collectives).  NULL selects HIP's default (null)

@@ -1336,17 +1336,20 @@ extern "C" int nbe_dist_energy(nbe_engine* e, double* ke, double* pe, double mom
     return NBE_OK;
 }
 
-extern "C" int nbe_dist_download(nbe_engine* e, uint64_t* index, double* pos, double* vel, double* mass, size_t* count)
+static int download_t(nbe_engine* e, uint64_t* index, double* pos, double* vel, double* mass, double* radius, size_t* count)
 {
-    NBE_TRY(check_dist(e, "nbe_dist_download"));
     DistState* d = e->dist;
     if (!count) { nbe_set_error("count is NULL"); return NBE_E_INVALID; }
     const size_t k = d->live_hi;
     *count = 0;
     if (k == 0) return NBE_OK;
     std::vector<uint32_t> ho(k);
-    std::vector<double> hp, hv;
+    std::vector<double> hp, hv, hr;
     std::vector<float> fp, fv;
+    if (radius) {
+        hr.resize(k);
+        NBE_HIP(hipMemcpyAsync(hr.data(), e->radius[e->cur], k * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    }
     NBE_HIP(hipMemcpyAsync(ho.data(), e->orig[e->orig_cur], k * 4, hipMemcpyDeviceToHost, e->stream));
     if (e->state64) {
         hp.resize(4 * k); hv.resize(4 * k);
@@ -1370,9 +1373,26 @@ extern "C" int nbe_dist_download(nbe_engine* e, uint64_t* index, double* pos, do
             if (vel) vel[3 * out + c] = e->state64 ? hv[4 * i + c] : (double)fv[4 * i + c];
         }
         if (mass) mass[out] = m;
+        if (radius) radius[out] = hr[i];
         if (index) index[out] = ho[i];
         out++;
     }
     *count = out;
     return NBE_OK;
+}
+
+extern "C" int nbe_dist_download(nbe_engine* e, uint64_t* index, double* pos, double* vel, double* mass, size_t* count)
+{
+    NBE_TRY(check_dist(e, "nbe_dist_download"));
+    try { return download_t(e, index, pos, vel, mass, nullptr, count); }
+    catch (const std::bad_alloc&) { nbe_set_error("out of host memory"); return NBE_E_NOMEM; }
+}
+
+extern "C" int nbe_dist_get_radius(nbe_engine* e, uint64_t* index, double* radius, size_t* count)
+{
+    NBE_TRY(check_dist(e, "nbe_dist_get_radius"));
+    if (!e->cfg.collisions) { nbe_set_error("nbe_dist_get_radius needs an engine created with collisions on"); return NBE_E_INVALID; }
+    if (!radius) { nbe_set_error("radius is NULL"); return NBE_E_INVALID; }
+    try { return download_t(e, index, nullptr, nullptr, nullptr, radius, count); }
+    catch (const std::bad_alloc&) { nbe_set_error("out of host memory"); return NBE_E_NOMEM; }
 }

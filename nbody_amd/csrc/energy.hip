@@ -121,9 +121,11 @@ int energy_compute(nbe_engine* e, double* ke, double* pe, double mom[3])
         nbe_set_error("nbe_energy in direct mode sums all pairs in fp64 and is limited to %d bodies", ENERGY_PAIR_SUM_MAX * 16);
         return NBE_E_UNSUPPORTED;
     }
+    // Tree mode: the sums are over the bodies the coming step will move, i.e. those inside the bound (tree.go:290-292); the
+    // build finds them (and the step reuses it).
+    if (e->cfg.mode == NBE_MODE_TREE && !e->prepared && e->n > 0) { NBE_TRY(tree_sort_and_build(e)); e->prepared = true; }
     if (tree_potential) {
         // instrumented walk over the current state: leaves each body's potential in e->acc[i].w
-        if (!e->prepared) { NBE_TRY(tree_sort_and_build(e)); e->prepared = true; }
         NBE_TRY(tree_forces(e, e->cur, 0, e->n, false, true, e->cur ^ 1));
     }
     int n_live = (int)e->n;

@@ -810,7 +810,7 @@ extern "C" int nbe_set_radius(nbe_engine* e, const double* radius)
 }
 extern "C" int nbe_get_radius(nbe_engine* e, double* radius, size_t* n_alive_out)
 {
-    NBE_NOT_DISTRIBUTED(e, "nbe_get_radius");
+    if (e && multi_is_distributed(e)) { NBE_GUARDED(multi_dist_get_radius(e, radius, n_alive_out)) }
     NBE_GUARDED(get_radius_impl(NBE_FIRST(e), radius, n_alive_out))
 }
 extern "C" int nbe_accel(nbe_engine* e, double* acc_xyz, uint8_t* alive_out)

@@ -95,6 +95,7 @@ struct Workers {
 struct DistFrameSlot {
     float* xyzm = nullptr;             // pinned, n_total x 4 floats
     uint32_t* orig = nullptr;          // pinned, n_total upload indices
+    float* radius = nullptr;           // pinned, n_total radii (collisions on)
     std::vector<hipEvent_t> done;      // per GPU: its part has landed
     size_t n = 0;
     int frame = 0;
@@ -113,6 +114,7 @@ struct DistFrames {
     std::vector<hipStream_t> side;
     std::vector<float4*> snap_xyzm;
     std::vector<uint32_t*> snap_orig;
+    std::vector<float*> snap_radius;                 // collisions on
     std::vector<hipEvent_t> snapped, sent;
     std::vector<char> sending;
     std::vector<DistFrameSlot> slots;
@@ -430,6 +432,12 @@ __global__ __launch_bounds__(256) void frame_narrow_kernel(const double4* __rest
     out[i] = make_float4((float)p.x, (float)p.y, (float)p.z, (float)p.w);
 }
 
+__global__ __launch_bounds__(256) void frame_narrow_radius_kernel(const double* __restrict__ radius, float* __restrict__ out, int n)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = (float)radius[i];
+}
+
 static void dist_frames_deliver(nbe_engine* e)
 {
     DistMulti* d = e->multi->dist;
@@ -452,14 +460,14 @@ static void dist_frames_deliver(nbe_engine* e)
             size_t keep = 0;
             for (size_t k = 0; k < s.n; k++) {
                 if (s.xyzm[4 * k + 3] == 0.0f && s.xyzm[4 * k] == parked) continue;
-                if (keep != k) { memcpy(s.xyzm + 4 * keep, s.xyzm + 4 * k, 4 * sizeof(float)); s.orig[keep] = s.orig[k]; }
+                if (keep != k) { memcpy(s.xyzm + 4 * keep, s.xyzm + 4 * k, 4 * sizeof(float)); s.orig[keep] = s.orig[k]; s.radius[keep] = s.radius[k]; }
                 keep++;
             }
             s.n = keep;
         }
         fs.ids_scratch.resize(s.n);
         for (size_t k = 0; k < s.n; k++) fs.ids_scratch[k] = s.orig[k] < d->ids.size() ? d->ids[s.orig[k]] : (uint64_t)s.orig[k];
-        fs.cb(fs.user, s.frame, s.n, s.xyzm, nullptr, fs.ids_scratch.data());
+        fs.cb(fs.user, s.frame, s.n, s.xyzm, e->cfg.collisions ? s.radius : nullptr, fs.ids_scratch.data());
         {
             std::lock_guard<std::mutex> lk(fs.mu);
             s.busy = false;
@@ -477,6 +485,7 @@ static void dist_frames_release(nbe_engine* e)
         if (g < fs.side.size() && fs.side[g]) { (void)hipStreamSynchronize(fs.side[g]); (void)hipStreamDestroy(fs.side[g]); }
         if (g < fs.snap_xyzm.size() && fs.snap_xyzm[g]) (void)hipFree(fs.snap_xyzm[g]);
         if (g < fs.snap_orig.size() && fs.snap_orig[g]) (void)hipFree(fs.snap_orig[g]);
+        if (g < fs.snap_radius.size() && fs.snap_radius[g]) (void)hipFree(fs.snap_radius[g]);
         if (g < fs.snapped.size() && fs.snapped[g]) (void)hipEventDestroy(fs.snapped[g]);
         if (g < fs.sent.size() && fs.sent[g]) (void)hipEventDestroy(fs.sent[g]);
         for (DistFrameSlot& s : fs.slots)
@@ -485,9 +494,10 @@ static void dist_frames_release(nbe_engine* e)
     for (DistFrameSlot& s : fs.slots) {
         if (s.xyzm) (void)hipHostFree(s.xyzm);
         if (s.orig) (void)hipHostFree(s.orig);
+        if (s.radius) (void)hipHostFree(s.radius);
     }
     fs.slots.clear();
-    fs.side.clear(); fs.snap_xyzm.clear(); fs.snap_orig.clear(); fs.snapped.clear(); fs.sent.clear(); fs.sending.clear();
+    fs.side.clear(); fs.snap_xyzm.clear(); fs.snap_orig.clear(); fs.snap_radius.clear(); fs.snapped.clear(); fs.sent.clear(); fs.sending.clear();
 }
 
 static int dist_frames_allocate(nbe_engine* e, int slots)
@@ -497,7 +507,7 @@ static int dist_frames_allocate(nbe_engine* e, int slots)
     DistFrames& fs = d->frames;
     const size_t G = m->subs.size();
     const size_t total = d->n_total > 0 ? d->n_total : 1;
-    fs.side.assign(G, nullptr); fs.snap_xyzm.assign(G, nullptr); fs.snap_orig.assign(G, nullptr);
+    fs.side.assign(G, nullptr); fs.snap_xyzm.assign(G, nullptr); fs.snap_orig.assign(G, nullptr); fs.snap_radius.assign(G, nullptr);
     fs.snapped.assign(G, nullptr); fs.sent.assign(G, nullptr); fs.sending.assign(G, 0);
     fs.slots.assign((size_t)slots, DistFrameSlot());
     for (DistFrameSlot& s : fs.slots) s.done.assign(G, nullptr);
@@ -507,6 +517,7 @@ static int dist_frames_allocate(nbe_engine* e, int slots)
         NBE_HIP(hipStreamCreateWithFlags(&fs.side[g], hipStreamNonBlocking));
         NBE_HIP(hipMalloc((void**)&fs.snap_xyzm[g], cap * sizeof(float4)));
         NBE_HIP(hipMalloc((void**)&fs.snap_orig[g], cap * sizeof(uint32_t)));
+        if (e->cfg.collisions) NBE_HIP(hipMalloc((void**)&fs.snap_radius[g], cap * sizeof(float)));
         NBE_HIP(hipEventCreateWithFlags(&fs.snapped[g], hipEventDisableTiming));
         NBE_HIP(hipEventCreateWithFlags(&fs.sent[g], hipEventDisableTiming));
         for (DistFrameSlot& s : fs.slots) NBE_HIP(hipEventCreateWithFlags(&s.done[g], hipEventDisableTiming));
@@ -514,6 +525,7 @@ static int dist_frames_allocate(nbe_engine* e, int slots)
     for (DistFrameSlot& s : fs.slots) {
         NBE_HIP(hipHostMalloc((void**)&s.xyzm, total * 4 * sizeof(float), hipHostMallocPortable));
         NBE_HIP(hipHostMalloc((void**)&s.orig, total * sizeof(uint32_t), hipHostMallocPortable));
+        if (e->cfg.collisions) NBE_HIP(hipHostMalloc((void**)&s.radius, total * sizeof(float), hipHostMallocPortable));
     }
     return NBE_OK;
 }
@@ -607,12 +619,18 @@ static int dist_frames_before_step(nbe_engine* e)
                 NBE_HIP(hipMemcpyAsync(fs.snap_xyzm[g], sub->posm[sub->cur], n * sizeof(float4), hipMemcpyDeviceToDevice, sub->stream));
             }
             NBE_HIP(hipMemcpyAsync(fs.snap_orig[g], sub->orig[sub->orig_cur], n * sizeof(uint32_t), hipMemcpyDeviceToDevice, sub->stream));
+            if (e->cfg.collisions) {
+                hipLaunchKernelGGL(frame_narrow_radius_kernel, dim3(cdiv(n, 256)), dim3(256), 0, sub->stream, (const double*)sub->radius[sub->cur],
+                                   fs.snap_radius[g], (int)n);
+                NBE_HIP(hipGetLastError());
+            }
         }
         NBE_HIP(hipEventRecord(fs.snapped[g], sub->stream));
         NBE_HIP(hipStreamWaitEvent(fs.side[g], fs.snapped[g], 0));
         if (n > 0) {
             NBE_HIP(hipMemcpyAsync(s.xyzm + 4 * at, fs.snap_xyzm[g], n * sizeof(float4), hipMemcpyDeviceToHost, fs.side[g]));
             NBE_HIP(hipMemcpyAsync(s.orig + at, fs.snap_orig[g], n * sizeof(uint32_t), hipMemcpyDeviceToHost, fs.side[g]));
+            if (e->cfg.collisions) NBE_HIP(hipMemcpyAsync(s.radius + at, fs.snap_radius[g], n * sizeof(float), hipMemcpyDeviceToHost, fs.side[g]));
         }
         NBE_HIP(hipEventRecord(s.done[g], fs.side[g]));
         NBE_HIP(hipEventRecord(fs.sent[g], fs.side[g]));
@@ -667,6 +685,33 @@ int multi_dist_download(nbe_engine* e, double* pos, double* vel, double* mass, u
         if (mass) mass[o] = ms[r][k];
         if (id) id[o] = where[o].first < d->ids.size() ? d->ids[where[o].first] : where[o].first;
     }
+    if (n_alive_out) *n_alive_out = where.size();
+    return NBE_OK;
+}
+
+// Radii of the survivors in upload order (the order of multi_dist_download).
+int multi_dist_get_radius(nbe_engine* e, double* radius, size_t* n_alive_out)
+{
+    MultiState* m = e->multi;
+    DistMulti* d = m->dist;
+    const size_t G = m->subs.size();
+    if (!e->cfg.collisions) { nbe_set_error("nbe_get_radius needs an engine created with collisions on"); return NBE_E_INVALID; }
+    if (n_alive_out) *n_alive_out = 0;
+    if (e->n == 0) return NBE_OK;
+    std::vector<std::vector<uint64_t>> idx(G);
+    std::vector<std::vector<double>> rad(G);
+    std::vector<size_t> cnt(G, 0);
+    NBE_TRY(d->pool.run([&](int r) -> int {
+        const size_t cap = d->capacity[(size_t)r];
+        idx[(size_t)r].resize(cap); rad[(size_t)r].resize(cap);
+        return nbe_dist_get_radius(m->subs[(size_t)r], idx[(size_t)r].data(), rad[(size_t)r].data(), &cnt[(size_t)r]);
+    }));
+    std::vector<std::pair<uint64_t, double>> where;
+    for (size_t r = 0; r < G; r++)
+        for (size_t k = 0; k < cnt[r]; k++) where.push_back({idx[r][k], rad[r][k]});
+    std::sort(where.begin(), where.end());
+    if (radius)
+        for (size_t o = 0; o < where.size(); o++) radius[o] = where[o].second;
     if (n_alive_out) *n_alive_out = where.size();
     return NBE_OK;
 }

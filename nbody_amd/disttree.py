@@ -58,6 +58,7 @@ def _declare(lib):
     lib.nbe_dist_layout.argtypes = [vp, C.c_int, C.POINTER(C.c_int32), vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int32),
                                     C.POINTER(C.c_int64)]
     lib.nbe_dist_download.argtypes = [vp, u64p, dp, dp, dp, C.POINTER(C.c_size_t)]
+    lib.nbe_dist_get_radius.argtypes = [vp, u64p, dp, C.POINTER(C.c_size_t)]
     for name in DIST_EXPORTS:
         getattr(lib, name).restype = C.c_int
     _declared = True
@@ -86,7 +87,7 @@ def layout(all_frags, sizes):
 
 DIST_EXPORTS = ["nbe_dist_layout", "nbe_dist_energy", "nbe_dist_set_total_mass", "nbe_dist_set_radius", "nbe_dist_upload", "nbe_dist_sample_keys", "nbe_dist_set_splitters", "nbe_dist_buffers", "nbe_dist_classify",
                 "nbe_dist_receive", "nbe_dist_build", "nbe_dist_export", "nbe_dist_assemble", "nbe_dist_advance",
-                "nbe_dist_download"]
+                "nbe_dist_download", "nbe_dist_get_radius"]
 
 
 def _dp(a):
@@ -227,6 +228,14 @@ class DistRank:
                                                 C.byref(k)))
         k = k.value
         return idx[:k], pos[:k], vel[:k], mass[:k]
+
+    def get_radius(self):
+        """Collisions on: (run-wide indices, radii) of this rank's live bodies, in the order of download()."""
+        n = self.capacity
+        idx = np.zeros(n, dtype=np.uint64); rad = np.zeros(n)
+        k = C.c_size_t(0)
+        self._check(self._lib.nbe_dist_get_radius(self._h, idx.ctypes.data_as(C.POINTER(C.c_uint64)), _dp(rad), C.byref(k)))
+        return idx[:k.value], rad[:k.value]
 
 
 # ---- communicators --------------------------------------------------------------------------------------------------

@@ -477,26 +477,28 @@ def test_collisions_behind_one_handle_and_a_radius_above_the_cap(gpu):
     frames_one, frames_dist = [], []
     with Engine(exact_sums=True, **kw) as one:
         one.upload(pos, vel, mass); one.set_radius(rad)
-        one.frame_stream_begin(lambda f, xyzm, ids, radius: frames_one.append((f, np.sort(ids))), every=2, slots=3)
+        one.frame_stream_begin(lambda f, xyzm, ids, radius: frames_one.append((f, np.sort(ids), radius[np.argsort(ids)])), every=2, slots=3)
         one.step(10)
         one.frame_stream_end()
-        want, wst = one.download(), one.stats()
+        want, wst, wrad = one.download(), one.stats(), one.get_radius()
     with Engine(devices=[0, 0, 0], distributed=True, **kw) as e:
         e.upload(pos, vel, mass); e.set_radius(rad)
-        e.frame_stream_begin(lambda f, xyzm, ids, radius: frames_dist.append((f, np.sort(ids))), every=2, slots=3)
+        e.frame_stream_begin(lambda f, xyzm, ids, radius: frames_dist.append((f, np.sort(ids), radius[np.argsort(ids)])), every=2, slots=3)
         e.step(10)
         e.frame_stream_end()
-        got, gst = e.download(), e.stats()
+        got, gst, grad = e.download(), e.stats(), e.get_radius()
         with pytest.raises(EngineError, match="right after"):
             e.set_radius(rad)
     assert wst.merges > 10 and gst.merges == wst.merges and gst.n_alive == wst.n_alive
     for a, w in zip(got, want):
         assert np.array_equal(a, w)
     # the frames hold the bodies that are left, absorbed ones gone at once (main.go:91-95)
-    assert [f for f, _ in frames_dist] == [f for f, _ in frames_one] == [0, 1, 2, 3, 4]
-    for (_, a), (_, w) in zip(frames_dist, frames_one):
-        assert np.array_equal(a, w)
+    assert [f[0] for f in frames_dist] == [f[0] for f in frames_one] == [0, 1, 2, 3, 4]
+    for (_, a, ra), (_, w, rw) in zip(frames_dist, frames_one):
+        assert np.array_equal(a, w) and np.array_equal(ra, rw)
     assert len(frames_one[-1][1]) < n
+    # merged bodies have grown (physics.go:139): the radii of the survivors, and those the frames carry
+    assert np.array_equal(grad, wrad) and grad.max() > rad.max()
     r = DistRank(0, 1, precision="f32", collisions=True)
     try:
         r.upload(2000, pos[:1000], vel[:1000], mass[:1000], 0)

@@ -175,3 +175,118 @@ def test_random_scenes_with_collisions_on_the_distributed_tree_equal_one_engine(
             assert np.array_equal(a, b), tag
         merges += out[0][5]
     assert merges > 20, merges                  # the scenes of a block do collide
+
+
+def _frame_sink(store):
+    def cb(frame, xyzm, ids, radius):
+        o = np.argsort(ids, kind="stable")
+        store.append((int(frame), ids[o], xyzm[o], None if radius is None else radius[o]))
+    return cb
+
+
+def _same_frames(a, b, tag):
+    assert [f[0] for f in a] == [f[0] for f in b], tag
+    for fa, fb in zip(a, b):
+        assert np.array_equal(fa[1], fb[1]), f"{tag}: bodies of frame {fa[0]}"
+        assert np.array_equal(fa[2], fb[2], equal_nan=True), f"{tag}: state of frame {fa[0]}"
+        assert (fa[3] is None) == (fb[3] is None), tag
+        if fa[3] is not None:
+            assert np.array_equal(fa[3], fb[3]), f"{tag}: radii of frame {fa[0]}"
+
+
+@pytest.mark.parametrize("block", range(2))
+def test_random_call_sequences_agree_between_engine_kinds(gpu, block):
+    """The same random sequence of calls (uploads of scenes of other sizes into the same engine, steps, downloads, stats,
+    radii, frame streams switched on and off, an upload while frames are streaming) on one engine and on an engine of
+    another kind: the key-range-distributed tree or replicated shards behind one handle, 2..5 GPUs' worth on this GPU.
+    Every answer must be the same bits.  (NBODY_FUZZ_SEEDS=k runs k sequences per block instead of six.)"""
+    import os
+    per = int(os.environ.get("NBODY_FUZZ_SEEDS", "6"))
+    for s in range(12000 + per * block, 12000 + per * (block + 1)):
+        rng = np.random.default_rng(s)
+        precision = str(rng.choice(["f32", "f64"]))
+        collide = bool(rng.random() < 0.5)
+        shards = int(rng.integers(2, 6))
+        theta = float(rng.choice([0.4, 0.7, 1.0]))
+        subject = dict(devices=[0] * shards, distributed=True) if rng.random() < 0.6 else dict(devices=[0] * shards, exact_sums=True)
+        tag0 = f"seed {s}: {precision} collide={collide} theta={theta} {subject}"
+        kw = dict(mode="tree", precision=precision, theta=theta, dt=200.0, collisions=collide)
+        engines = [Engine(exact_sums=True, **kw), Engine(**subject, **kw)]
+        frames = [[], []]
+        streaming = False
+        log = []
+        try:
+            ops = ["upload"] + [str(o) for o in rng.choice(["upload", "step", "step", "step", "download", "stats", "radius", "frames", "energy"],
+                                                           size=int(rng.integers(4, 10)))] + ["download", "stats"]
+            n = 0
+            for op in ops:
+                if op == "upload":
+                    kind, pos, vel, mass, rad = scene(rng)
+                    n = len(mass)
+                    if collide:
+                        if kind == "clustered":
+                            rad = rad * 0.1
+                        elif kind in ("uniform", "mixed") and n > 1:
+                            pos = pos * (60.0 * n ** (1 / 3) / 6e4)
+                        elif kind == "line" and n > 1:
+                            pos = pos * (60.0 * n / 6e4)
+                    ids = None
+                    if rng.random() < 0.3:            # the host's own identities instead of 0..n-1
+                        ids = rng.permutation(4 * n + 3)[:n].astype(np.uint64) + np.uint64(1 << 40)
+                    log.append(f"upload {kind} n={n}" + (" own ids" if ids is not None else ""))
+                    for e in engines:
+                        e.upload(pos, vel, mass, ids)
+                        if collide and n:
+                            e.set_radius(rad)
+                    if streaming:                     # an upload ends the stream and delivers what was queued
+                        streaming = False
+                        _same_frames(frames[0], frames[1], f"{tag0} {log}")
+                elif op == "step":
+                    k = int(rng.choice([1, 2, 5]))
+                    log.append(f"step {k}")
+                    for e in engines:
+                        e.step(k)
+                elif op == "download":
+                    log.append("download")
+                    a, b = (e.download() for e in engines)
+                    for x, y in zip(a, b):              # (a body uploaded with a NaN coordinate keeps it until a step drops it)
+                        assert np.array_equal(x, y, equal_nan=x.dtype.kind == "f"), f"{tag0} {log}"
+                elif op == "stats":
+                    log.append("stats")
+                    a, b = (e.stats() for e in engines)
+                    assert (a.n, a.n_alive, a.steps) == (b.n, b.n_alive, b.steps), f"{tag0} {log}"
+                    if collide:
+                        assert a.merges == b.merges, f"{tag0} {log}"
+                elif op == "energy" and n:
+                    log.append("energy")
+                    (ka, pa, ma), (kb, pb, mb) = (e.energy() for e in engines)
+                    # (one engine sums the potential of so few bodies over all pairs; the distributed tree always sums it
+                    # over the nodes its walk accepts)
+                    ptol = 0.1 if subject.get("distributed") else 1e-9
+                    assert abs(ka - kb) <= 1e-12 * abs(ka) and abs(pa - pb) <= ptol * abs(pa), f"{tag0} {log}: {ka} {kb} {pa} {pb}"
+                    assert np.abs(ma - mb).max() <= 1e-12 * (np.abs(ma).max() + 1e-300), f"{tag0} {log}"
+                elif op == "radius" and collide:
+                    log.append("radius")
+                    a, b = (e.get_radius() for e in engines)
+                    assert np.array_equal(a, b), f"{tag0} {log}"
+                elif op == "frames":
+                    if streaming:
+                        log.append("frames off")
+                        for e in engines:
+                            e.frame_stream_end()
+                        streaming = False
+                        _same_frames(frames[0], frames[1], f"{tag0} {log}")
+                    elif n:
+                        every, slots = int(rng.integers(1, 4)), int(rng.integers(2, 5))
+                        log.append(f"frames on every={every} slots={slots}")
+                        frames = [[], []]
+                        for e, sink in zip(engines, frames):
+                            e.frame_stream_begin(_frame_sink(sink), every=every, slots=slots)
+                        streaming = True
+            if streaming:
+                for e in engines:
+                    e.frame_stream_end()
+                _same_frames(frames[0], frames[1], f"{tag0} {log} end")
+        finally:
+            for e in engines:
+                e.close()
