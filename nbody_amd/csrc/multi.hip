@@ -588,7 +588,7 @@ static int dist_frames_before_step(nbe_engine* e)
     std::vector<size_t> live(G, 0);
     size_t total = 0;
     for (size_t g = 0; g < G; g++) { live[g] = dist_live_slots(m->subs[g]); total += live[g]; }
-    if (total == 0) return NBE_OK;
+    if (d->n_total == 0) return NBE_OK;              // (a run whose bodies have all left the bound still sends its frames, empty)
     if (total > d->n_total) { nbe_set_error("the GPUs hold %zu bodies of %zu", total, d->n_total); return NBE_E_DEVICE; }
     fs.have_last = true; fs.last_k = k;
     int slot = -1;
