@@ -164,3 +164,27 @@ def test_host_distributed_tree_streams_the_frames_of_one_gpu(gpu, tmp_path):
     first = read_frame(tmp_path / "dist" / files[0])
     one = read_frame(tmp_path / "one" / files[0])
     assert np.array_equal(first[np.argsort(first["id"])]["xyzmr"], one[np.argsort(one["id"])]["xyzmr"])
+
+
+@pytest.mark.gpu
+def test_host_distributed_tree_with_collisions_equals_one_gpu(gpu, tmp_path):
+    """The reference's default run has collisions on (main.go:24).  -distributed with them, fp64 (both runs then sum their
+    cells exactly): the frame files, radii included, and the state saved at the end hold the rows of a one-GPU run bit
+    for bit."""
+    from nbody_amd import gobfile as G
+    common = ["-n", "3000", "-y", "0.002", "-tree", "-seed", "3", "-theta", "0.7", "-precision", "f64", "-save"]
+    for name, extra in (("dist", ["-devices", "0,0,0", "-distributed"]), ("one", [])):
+        d = tmp_path / name; d.mkdir()
+        r = run(common + extra + ["-frames-dir", "frames"], d)
+        assert r.returncode == 0, r.stdout.decode()
+    files = sorted(os.listdir(tmp_path / "dist" / "frames"))
+    assert files == sorted(os.listdir(tmp_path / "one" / "frames")) and len(files) == 18
+    for name in (files[0], files[8], files[17]):
+        a, b = read_frame(tmp_path / "dist" / "frames" / name), read_frame(tmp_path / "one" / "frames" / name)
+        a, b = a[np.argsort(a["id"])], b[np.argsort(b["id"])]
+        assert np.array_equal(a["id"], b["id"]) and np.array_equal(a["xyzmr"], b["xyzmr"])
+    sa = G.import_frame_data(str(tmp_path / "dist" / f"{18:010d}.data"))
+    sb = G.import_frame_data(str(tmp_path / "one" / f"{18:010d}.data"))
+    assert sa[0] == sb[0] == 18
+    for x, y in zip(sa[1:], sb[1:]):
+        assert np.array_equal(x, y)
