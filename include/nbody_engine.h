@@ -286,7 +286,7 @@ int nbe_dist_set_total_mass(nbe_engine *e, double total_mass);
  * that are at most four radii wide; nbe_dist_set_splitters moves every splitter down to the border of a cell at least four
  * caps wide, so such cells, the pairs a search can queue and the pairs that share a body all lie on one rank, and every
  * rank searches, merges (its own pairs in the reference's queue order) and updates for itself after the force pass.  Queue
- * lengths, merges and survivors equal those of one engine.  A body whose radius grows beyond the cap, or more than 16,384
+ * lengths, merges and survivors equal those of one engine.  A body whose radius grows beyond the cap, or more than 262,144
  * bodies of one rank queueing pairs in one step, makes nbe_dist_advance fail with NBE_E_UNSUPPORTED.  Right after
  * nbe_dist_upload, before nbe_dist_set_splitters. */
 int nbe_dist_set_radius(nbe_engine *e, const double *radius, double radius_cap);
@@ -296,6 +296,14 @@ int nbe_dist_buffers(nbe_engine *e, nbe_dist_buffers_t *out);
 /* Packs the bodies that belong to other ranks into the outbox (those for rank d start at record
  * send_counts[0] + ... + send_counts[d-1]) and removes them here.  Synchronises. */
 int nbe_dist_classify(nbe_engine *e, uint32_t *send_counts);
+/* After nbe_dist_classify: the number of records this rank can take in the nbe_dist_receive that follows (its free
+ * slots, those of its leavers included).  A host adds up what every rank is about to be sent; where that exceeds a rank's
+ * room (the bodies' distribution over key space changed more in one step than the spare slots allow for), every rank calls
+ * nbe_dist_unclassify, new splitters are chosen from the bodies as they now are, and the step starts again with
+ * nbe_dist_classify (nbody_amd/disttree.py and the engine's own driver do this). */
+int nbe_dist_room(nbe_engine *e, uint64_t *room);
+/* Undoes the last nbe_dist_classify (before any nbe_dist_receive): the leavers return from the outbox to their slots. */
+int nbe_dist_unclassify(nbe_engine *e);
 /* Takes over the first k records of the inbox. */
 int nbe_dist_receive(nbe_engine *e, size_t k);
 /* Sorts the rank's bodies, builds its tree and lists its fragments in key order (at most `max`).  boxes: up to

@@ -21,7 +21,7 @@
 
 struct Cell { double cx, cy, cz, w; };
 
-#define RANK_QUEUE_CAP 16384     // bodies of one rank of the distributed tree that may queue pairs in one step
+#define RANK_QUEUE_CAP 262144    // bodies of one rank of the distributed tree that may queue pairs in one step
 
 // Centre and edge of the depth-`level` cell that contains `key`: exact for a power-of-two bound, and equal to
 // what octantBound (tree.go:101-110) reaches by repeated quarter-edge translations.
@@ -211,13 +211,22 @@ __global__ __launch_bounds__(256) void collide_search_kernel(const CNode* __rest
 __global__ __launch_bounds__(256) void collide_rank_kernel(const uint4* __restrict__ list, const uint32_t* __restrict__ meta, int cap,
                                                            uint4* __restrict__ sorted)
 {
+    // (all pairs of entries: the indices pass through LDS 256 at a time and every thread reads them as broadcasts; the
+    // full list of 262,144 entries, far beyond any step seen, takes about two milliseconds)
+    __shared__ uint32_t idx[256];
     const int m = (int)min(meta[0], (uint32_t)cap);
+    if ((int)blockIdx.x * 256 >= m) return;            // (the whole workgroup alike)
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= m) return;
-    const uint4 me = list[i];
+    const uint4 me = i < m ? list[i] : make_uint4(0u, 0u, 0u, 0u);
     int before = 0;
-    for (int j = 0; j < m; j++) before += list[j].x < me.x ? 1 : 0;
-    sorted[before] = me;
+    for (int base = 0; base < m; base += 256) {
+        __syncthreads();
+        if (base + (int)threadIdx.x < m) idx[threadIdx.x] = list[base + threadIdx.x].x;
+        __syncthreads();
+        const int lim = min(256, m - base);
+        for (int j = 0; j < lim; j++) before += idx[j] < me.x ? 1 : 0;
+    }
+    if (i < m) sorted[before] = me;
 }
 
 // One wave: running sum of the entries' pair counts in queue order; every listed body learns where its pairs go.

@@ -60,7 +60,7 @@ struct DistState {
     uint16_t* dest_of = nullptr;        // per slot, left by the last classify: 0 = stays (or no body), d + 1 = moves to rank d
     uint32_t n_free = 0;
     int frag_hint = 0;                  // fragments of the last build (sizes the grid of the next build's box kernel)
-    bool classified = false, built = false, exported = false, assembled = false, have_total = false;
+    bool classified = false, received = false, built = false, exported = false, assembled = false, have_total = false;
     // fragments of the last build
     nbe_fragment_t* d_frags = nullptr;
     int* d_nfrag = nullptr;             // [0] fragments of the last build, [2..5] a copy of the build's counters (one read-back for both)
@@ -485,13 +485,31 @@ __global__ __launch_bounds__(256) void pack_kernel(const uint16_t* __restrict__ 
         outbox[(size_t)rec * at + 1] = v;
         if (radius) { S4 r; r.x = 0; r.y = 0; r.z = 0; r.w = 0; put_radius(r, radius[i]); outbox[(size_t)rec * at + 2] = r; }
         free_slots[base[world] + mine_all[k]] = (uint32_t)i;
-        // the slot now holds a massless body parked outside the bound
+        // the slot now holds a massless body parked outside the bound (and, where the velocity element carries an index
+        // in a record, the place of its record in the outbox: nbe_dist_unclassify brings the body back from there)
         p.x = lox + 2.0 * W; p.y = loy + 2.0 * W; p.z = loz + 2.0 * W; p.w = 0;
-        v.x = 0; v.y = 0; v.z = 0; v.w = 0;
+        v.x = 0; v.y = 0; v.z = 0; put_index(v, at);
         posm[i] = p;
         vel[i] = v;
         if (mirror) mirror[i] = make_float4((float)p.x, (float)p.y, (float)p.z, 0.0f);
     }
+}
+
+// Undoes pack_kernel: every slot vacated by the last classify takes its body back from the outbox.
+template <typename S4>
+__global__ __launch_bounds__(256) void unpack_kernel(const uint32_t* __restrict__ free_slots, int n_free, const S4* __restrict__ outbox,
+                                                     S4* __restrict__ posm, S4* __restrict__ vel, float4* __restrict__ mirror, int rec)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= n_free) return;
+    const uint32_t slot = free_slots[j];
+    const uint32_t at = get_index(vel[slot]);
+    const S4 p = outbox[(size_t)rec * at];
+    S4 v = outbox[(size_t)rec * at + 1];
+    v.w = 0;
+    posm[slot] = p;
+    vel[slot] = v;
+    if (mirror) mirror[slot] = make_float4((float)p.x, (float)p.y, (float)p.z, (float)p.w);
 }
 
 template <typename R4, typename S4>
@@ -538,8 +556,37 @@ extern "C" int nbe_dist_classify(nbe_engine* e, uint32_t* send_counts)
     case NBE_PREC_MIXED: rc = classify_t<float4, double4>(e, send_counts); break;
     case NBE_PREC_F64: rc = classify_t<double4, double4>(e, send_counts); break;
     }
-    if (rc == NBE_OK) { d->classified = true; d->built = false; d->exported = false; d->assembled = false; e->prepared = false; e->keys_sorted = false; }
+    if (rc == NBE_OK) { d->classified = true; d->received = false; d->built = false; d->exported = false; d->assembled = false; e->prepared = false; e->keys_sorted = false; }
     return rc;
+}
+
+extern "C" int nbe_dist_room(nbe_engine* e, uint64_t* room)
+{
+    NBE_TRY(check_dist(e, "nbe_dist_room"));
+    if (!room) { nbe_set_error("room is NULL"); return NBE_E_INVALID; }
+    const DistState* d = e->dist;
+    *room = (uint64_t)(d->cap - d->live_hi) + d->n_free;
+    return NBE_OK;
+}
+
+extern "C" int nbe_dist_unclassify(nbe_engine* e)
+{
+    NBE_TRY(check_dist(e, "nbe_dist_unclassify"));
+    DistState* d = e->dist;
+    if (!d->classified || d->received) { nbe_set_error("nbe_dist_unclassify comes between nbe_dist_classify and nbe_dist_receive"); return NBE_E_INVALID; }
+    if (d->n_free > 0) {
+        float4* mirror = e->cfg.precision == NBE_PREC_MIXED ? e->mirror[e->cur] : nullptr;
+        if (e->state64)
+            hipLaunchKernelGGL((unpack_kernel<double4>), dim3(cdiv(d->n_free, 256)), dim3(256), 0, e->stream, d->free_slots, (int)d->n_free,
+                               (const double4*)d->outbox, (double4*)e->posm[e->cur], (double4*)e->vel[e->cur], mirror, d->rec_elems);
+        else
+            hipLaunchKernelGGL((unpack_kernel<float4>), dim3(cdiv(d->n_free, 256)), dim3(256), 0, e->stream, d->free_slots, (int)d->n_free,
+                               (const float4*)d->outbox, (float4*)e->posm[e->cur], (float4*)e->vel[e->cur], mirror, d->rec_elems);
+        NBE_HIP(hipGetLastError());
+    }
+    d->n_free = 0;
+    d->classified = false;
+    return NBE_OK;
 }
 
 template <typename S4>
@@ -585,6 +632,7 @@ extern "C" int nbe_dist_receive(nbe_engine* e, size_t k)
     }
     d->live_hi += extra;
     d->n_free = d->n_free > k ? d->n_free - (uint32_t)k : 0;     // (slots still vacant are parked bodies: the sort drops them)
+    d->received = true;
     return NBE_OK;
 }
 

@@ -351,8 +351,33 @@ static int dist_prepare(nbe_engine* e)
         d->want_rebalance = false;
     }
     // bodies that crossed a splitter go to their new owner
-    d->send.assign(G, std::vector<uint32_t>(G, 0));
-    NBE_TRY(d->pool.run([&](int r) -> int { return nbe_dist_classify(m->subs[(size_t)r], d->send[(size_t)r].data()); }));
+    for (int attempt = 0;; attempt++) {
+        d->send.assign(G, std::vector<uint32_t>(G, 0));
+        std::vector<uint64_t> room(G, 0);
+        NBE_TRY(d->pool.run([&](int r) -> int {
+            NBE_TRY(nbe_dist_classify(m->subs[(size_t)r], d->send[(size_t)r].data()));
+            return nbe_dist_room(m->subs[(size_t)r], &room[(size_t)r]);
+        }));
+        bool fits = true;
+        for (size_t q = 0; q < G; q++) {
+            uint64_t bound = 0;
+            for (size_t r = 0; r < G; r++) bound += d->send[r][q];
+            if (bound > room[q]) fits = false;
+        }
+        if (fits) break;
+        // More bodies are bound for some GPU than it has room for: the distribution over key space changed more in one
+        // step than the spare slots allow.  The leavers go back to their slots, new splitters are chosen from the bodies
+        // as they are now, and the classification is done again.
+        if (attempt == 1) {
+            nbe_set_error("the GPUs' capacities do not hold the bodies even with new splitters%s",
+                          e->cfg.collisions ? " (with collisions on a splitter sits on the border of a cell at least four radius caps wide: "
+                                              "the bodies may span too few such cells to be shared out evenly)" : "");
+            return NBE_E_NOMEM;
+        }
+        NBE_TRY(d->pool.run([&](int r) -> int { return nbe_dist_unclassify(m->subs[(size_t)r]); }));
+        NBE_TRY(dist_distribute(e));
+        d->rebalances++;
+    }
     d->frags.assign(G, std::vector<nbe_fragment_t>(NBE_DIST_MAX_FRAGMENTS));
     d->boxes.assign(G, std::vector<double>(NBE_DIST_MAX_BOXES * 6, 0.0));
     d->nboxes.assign(G, 0); d->nfrags.assign(G, 0); d->live.assign(G, 0);

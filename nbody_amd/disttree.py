@@ -50,6 +50,8 @@ def _declare(lib):
     lib.nbe_dist_buffers.argtypes = [vp, C.POINTER(DistBuffers)]
     lib.nbe_dist_classify.argtypes = [vp, C.POINTER(C.c_uint32)]
     lib.nbe_dist_receive.argtypes = [vp, C.c_size_t]
+    lib.nbe_dist_room.argtypes = [vp, u64p]
+    lib.nbe_dist_unclassify.argtypes = [vp]
     lib.nbe_dist_build.argtypes = [vp, vp, C.c_int, C.POINTER(C.c_int), dp, C.POINTER(C.c_int), u64p]
     lib.nbe_dist_export.argtypes = [vp, vp, C.POINTER(C.c_int), dp, C.POINTER(C.c_int), C.POINTER(C.c_int32), u64p]
     lib.nbe_dist_assemble.argtypes = [vp, C.POINTER(C.c_int32), u64p]
@@ -87,7 +89,7 @@ def layout(all_frags, sizes):
 
 DIST_EXPORTS = ["nbe_dist_layout", "nbe_dist_energy", "nbe_dist_set_total_mass", "nbe_dist_set_radius", "nbe_dist_upload", "nbe_dist_sample_keys", "nbe_dist_set_splitters", "nbe_dist_buffers", "nbe_dist_classify",
                 "nbe_dist_receive", "nbe_dist_build", "nbe_dist_export", "nbe_dist_assemble", "nbe_dist_advance",
-                "nbe_dist_download", "nbe_dist_get_radius"]
+                "nbe_dist_download", "nbe_dist_get_radius", "nbe_dist_room", "nbe_dist_unclassify"]
 
 
 def _dp(a):
@@ -172,6 +174,16 @@ class DistRank:
         counts = np.zeros(self.world, dtype=np.uint32)
         self._check(self._lib.nbe_dist_classify(self._h, counts.ctypes.data_as(C.POINTER(C.c_uint32))))
         return counts
+
+    def room(self):
+        """After classify(): how many records this rank can take in the receive() that follows."""
+        v = C.c_uint64(0)
+        self._check(self._lib.nbe_dist_room(self._h, C.byref(v)))
+        return int(v.value)
+
+    def unclassify(self):
+        """Undoes the last classify() (before any receive()): the leavers return to their slots."""
+        self._check(self._lib.nbe_dist_unclassify(self._h))
 
     def receive(self, k):
         self._check(self._lib.nbe_dist_receive(self._h, int(k)))
@@ -481,10 +493,22 @@ class DistributedTree:
             self._want_rebalance = False
             self._mark("rebalance")
         # bodies that crossed a splitter go to their new owner
-        send = [r.classify() for r in R]
-        self._mark("classify")
+        send, recv = self._classify()
+        if recv is None:
+            # More bodies are bound for some rank than it has room for: the distribution over key space changed more in
+            # one step than the spare slots allow.  Everybody sees the same counts and takes the same way out: the
+            # leavers go back to their slots, new splitters are chosen from the bodies as they are now, and the
+            # classification is done again.
+            for r in R:
+                r.unclassify()
+            self.distribute()
+            self.rebalances += 1
+            self._mark("rebalance")
+            send, recv = self._classify()
+            if recv is None:
+                raise EngineError("the ranks' capacities do not hold the bodies even with new splitters: upload with more room per rank")
         unit = R[0].buffers.record_bytes
-        recv = self.comm.alltoall(R, "outbox", "inbox", send, unit)
+        self.comm.alltoall(R, "outbox", "inbox", send, unit, recv_counts=recv)
         for r, rc in zip(R, recv):
             r.receive(sum(rc))
         self._mark("migrate")
@@ -527,6 +551,20 @@ class DistributedTree:
             r.assemble(np.concatenate(imp) if len(imp) else np.zeros(0, np.int32), offs)
         self._prepared = True
         self._mark("exchange_assemble")
+
+    def _classify(self):
+        """classify() on the ranks of this process, then everybody's counts and room in one gather.  Returns (send, recv)
+        with recv[k][src] = records rank k of this process receives from rank src, or (send, None) when some rank of the
+        run has less room than what is bound for it."""
+        R, W = self.ranks, self.world
+        send = [r.classify() for r in R]
+        self._mark("classify")
+        got = self.comm.allgather_many([[np.asarray(s, dtype=np.int64), np.array([r.room()], dtype=np.int64)] for s, r in zip(send, R)])
+        rows = [g[0] for g in got[0]]                  # rows[src][dst], the same on every rank
+        room = [int(g[1][0]) for g in got[0]]
+        if any(sum(int(rows[src][q]) for src in range(W)) > room[q] for q in range(W)):
+            return send, None
+        return send, [[int(rows[src][r.rank]) for src in range(W)] for r in R]
 
     def download(self):
         """(index, pos, vel, mass) of the bodies of the ranks in this process, sorted by run-wide index."""

@@ -157,7 +157,7 @@ def test_call_order_and_unsupported_configurations(gpu):
 
 def test_a_rank_that_runs_out_of_slots_says_so(gpu):
     b = physics.plummer(4000, seed=2, a=2e3)
-    with pytest.raises(EngineError, match="slots are free|too small"):
+    with pytest.raises(EngineError, match="slots are free|too small|do not hold the bodies"):
         # all bodies start on rank 0 and rank 1 has room for 1000
         ranks = [DistRank(r, 2, precision="f32") for r in range(2)]
         try:
@@ -209,6 +209,55 @@ def test_one_process_per_rank_with_collisions(gpu, tmp_path):
     assert np.array_equal(idx[order], wid)
     for key, want in (("pos", wp), ("vel", wv), ("mass", wm)):
         assert np.array_equal(np.concatenate([r[key] for r in res])[order], want)
+
+
+def test_a_step_that_sends_most_bodies_elsewhere_gets_new_splitters_first(gpu):
+    """Bodies on a line (y = z = 0 exactly) with random velocities: all keys lie in octants 6 and 7 at first, and after one
+    step the bodies fill all eight octants, so seven eighths of them are bound for rank 0 of two: more than its spare slots
+    hold.  Every rank sees the counts and the room (nbe_dist_room), the leavers go back to their slots
+    (nbe_dist_unclassify), new splitters are chosen and the step goes on: the same bits as one engine, from the Python
+    host and from the engine's own driver."""
+    rng = np.random.default_rng(77)
+    n = 40000
+    pos = np.zeros((n, 3)); pos[:, 0] = rng.uniform(-3e4, 3e4, n)
+    vel = rng.normal(0, 1e-2, (n, 3)); mass = np.abs(rng.normal(1e4, 5e3, n)) + 1.0
+    kw = dict(precision="f32", theta=0.6, dt=200.0)
+    with Engine(mode="tree", exact_sums=True, **kw) as one:
+        one.upload(pos, vel, mass)
+        one.step(3)
+        want = one.download()
+    with Engine(mode="tree", devices=[0, 0], distributed=True, **kw) as e:
+        e.upload(pos, vel, mass)
+        e.step(3)
+        got = e.download()
+    for a, w in zip(got, want):
+        assert np.array_equal(a, w)
+    world, per = 2, n // 2
+    ranks = [DistRank(r, world, **kw) for r in range(world)]
+    try:
+        for r in ranks:
+            a = r.rank * per
+            r.upload(int(per * 1.25) + 4096, pos[a:a + per], vel[a:a + per], mass[a:a + per], a)
+            r.use_torch_stream()
+        dt = DistributedTree(ranks, LocalComm(world), rebalance_at=None)
+        dt.distribute()
+        dt.step(3)
+        assert dt.rebalances == 1                          # (rebalance_at=None: only the overflow could have asked for it)
+        idx, p, v, m = dt.download()
+        # undone by hand: classify, take it back, classify again gives the same counts and loses nobody
+        first = [r.classify() for r in ranks]
+        for r in ranks:
+            r.unclassify()
+        again = [r.classify() for r in ranks]
+        assert all(np.array_equal(a, b) for a, b in zip(first, again)) and sum(int(c.sum()) for c in first) > 0
+        for r in ranks:
+            r.unclassify()
+        idx2, p2, v2, m2 = dt.download()
+    finally:
+        for r in ranks:
+            r.close()
+    assert np.array_equal(idx, want[3]) and np.array_equal(p, want[0]) and np.array_equal(v, want[1]) and np.array_equal(m, want[2])
+    assert np.array_equal(idx2, idx) and np.array_equal(p2, p) and np.array_equal(v2, v) and np.array_equal(m2, m)
 
 
 def test_new_splitters_during_a_run_change_nothing_but_the_owners(gpu):

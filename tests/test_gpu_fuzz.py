@@ -6,13 +6,18 @@ import numpy as np
 import pytest
 
 from nbody_amd import Engine
+from nbody_amd.engine import EngineError
 from oracle import oracle as O
 
 pytestmark = pytest.mark.gpu
 
 
-def scene(rng):
+def scene(rng, scale=1):
+    """scale > 1 (engine-against-engine tests only, NBODY_FUZZ_SCALE): the larger sizes times that factor, beyond the
+    8,192 bodies up to which one workgroup sorts and scans."""
     n = int(rng.choice([0, 1, 2, 3, 5, 17, 63, 64, 65, 200, 777, 1500, 3000]))
+    if n >= 200:
+        n *= scale
     kind = rng.choice(["uniform", "clustered", "lattice", "line", "mixed"])
     if kind == "uniform":
         pos = rng.uniform(-3e4, 3e4, (n, 3))
@@ -118,7 +123,7 @@ def test_random_scenes_on_the_distributed_tree_equal_one_engine(gpu, block):
     per = int(os.environ.get("NBODY_FUZZ_SEEDS", "10"))
     for s in range(9500 + per * block, 9500 + per * (block + 1)):
         rng = np.random.default_rng(s)
-        kind, pos, vel, mass, rad = scene(rng)
+        kind, pos, vel, mass, rad = scene(rng, int(os.environ.get("NBODY_FUZZ_SCALE", "1")))
         n = len(mass)
         precision = str(rng.choice(["f32", "mixed", "f64"]))
         shards = int(rng.integers(2, 7)); nsteps = int(rng.choice([1, 3, 6]))
@@ -134,7 +139,15 @@ def test_random_scenes_on_the_distributed_tree_equal_one_engine(gpu, block):
         assert np.array_equal(out[0][3], out[1][3]), tag
         if precision == "mixed":
             if len(out[0][0]):
-                assert np.abs(out[0][0] - out[1][0]).max() <= 1e-9 * (np.abs(out[0][0]).max() + 1e-30), tag
+                # (the wavefronts hold other bodies, so the fp32 partial sums of a body break at other visits; beside a body
+                # of 1e9 kg a dozen metres away, which the denser scenes of NBODY_FUZZ_SCALE have, that shows at 3e-9)
+                # (and a few unsoftened pairs less than a metre apart amplify it from step to step: the denser scenes are
+                # judged by their 99th percentile, with a loose bound on the worst body)
+                diff, extent = np.abs(out[0][0] - out[1][0]).max(axis=1), np.abs(out[0][0]).max() + 1e-30
+                if os.environ.get("NBODY_FUZZ_SCALE", "1") == "1":
+                    assert diff.max() <= 1e-9 * extent, tag
+                else:
+                    assert np.quantile(diff, 0.99) <= 1e-8 * extent and diff.max() <= 1e-4 * extent, tag
         else:
             assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1]), tag
 
@@ -149,7 +162,7 @@ def test_random_scenes_with_collisions_on_the_distributed_tree_equal_one_engine(
     merges = 0
     for s in range(9700 + per * block, 9700 + per * (block + 1)):
         rng = np.random.default_rng(s)
-        kind, pos, vel, mass, rad = scene(rng)
+        kind, pos, vel, mass, rad = scene(rng, int(os.environ.get("NBODY_FUZZ_SCALE", "1")))
         n = len(mass)
         if kind == "clustered":
             rad = rad * 0.1                     # (clusters a metre wide would merge into one body at once)
@@ -162,14 +175,20 @@ def test_random_scenes_with_collisions_on_the_distributed_tree_equal_one_engine(
         theta = float(rng.choice([0.3, 0.6, 1.0]))
         tag = f"seed {s}: {kind} n={n} {precision} shards={shards} steps={nsteps} theta={theta}"
         out = []
-        for kw in (dict(exact_sums=True), dict(devices=[0] * shards, distributed=True)):
-            with Engine(mode="tree", precision=precision, theta=theta, dt=200.0, collisions=True, **kw) as e:
-                e.upload(pos, vel, mass)
-                if n:
-                    e.set_radius(rad)
-                e.step(nsteps)
-                st = e.stats()
-                out.append(e.download() + (int(st.n_alive), int(st.merges)))
+        try:
+            for kw in (dict(exact_sums=True), dict(devices=[0] * shards, distributed=True)):
+                with Engine(mode="tree", precision=precision, theta=theta, dt=200.0, collisions=True, **kw) as e:
+                    e.upload(pos, vel, mass)
+                    if n:
+                        e.set_radius(rad)
+                    e.step(nsteps)
+                    st = e.stats()
+                    out.append(e.download() + (int(st.n_alive), int(st.merges)))
+        except EngineError as ex:
+            # tens of thousands of bodies crowded into fewer 4096 m cells than there are shards (the splitters sit on those
+            # cells' borders for radii of 40 m) cannot be shared out: refused with a message, not a wrong answer
+            assert "span too few such cells" in str(ex) and n > 20000, f"{tag}: {ex}"
+            continue
         assert out[0][4:] == out[1][4:], tag
         for a, b in zip(out[0][:4], out[1][:4]):
             assert np.array_equal(a, b), tag
@@ -238,7 +257,7 @@ def test_random_call_sequences_agree_between_engine_kinds(gpu, block):
             n = 0
             for op in ops:
                 if op == "upload":
-                    kind, pos, vel, mass, rad = scene(rng)
+                    kind, pos, vel, mass, rad = scene(rng, int(os.environ.get("NBODY_FUZZ_SCALE", "1")) if mode == "tree" else 1)
                     n = len(mass)
                     if mode == "direct":              # (no bound there, and coincident bodies are a stated deviation)
                         pos = np.nan_to_num(pos)
@@ -312,6 +331,10 @@ def test_random_call_sequences_agree_between_engine_kinds(gpu, block):
                 for e in engines:
                     e.frame_stream_end()
                 _same_frames(frames[0], frames[1], f"{tag0} {log} end", tol)
+        except EngineError as ex:
+            # (NBODY_FUZZ_SCALE only: a crowd that spans fewer 4096 m cells than there are shards cannot be shared out with
+            # collisions on, see test_random_scenes_with_collisions_...; the sequence ends there)
+            assert "span too few such cells" in str(ex) and n > 20000, f"{tag0} {log}: {ex}"
         finally:
             for e in engines:
                 e.close()
