@@ -117,6 +117,13 @@ def main():
             bodies = physics.Bodies(rng.uniform(-150.0, 150.0, (n, 3)), rng.normal(0, 1e-3, (n, 3)), np.abs(rng.normal(1e3, 500, n)) + 1)
             rad = np.random.default_rng(6).uniform(0.5, 3.0, n)
             extra = dict(collisions=True, dt=50.0)
+        if "line" in sys.argv[7:]:
+            # bodies on a line with random velocities: after one step most of them belong to another rank (the ranks must
+            # agree to take their leavers back and choose new splitters)
+            rng = np.random.default_rng(77)
+            pos = np.zeros((n, 3)); pos[:, 0] = rng.uniform(-3e4, 3e4, n)
+            bodies = physics.Bodies(pos, rng.normal(0, 1e-2, (n, 3)), np.abs(rng.normal(1e4, 5e3, n)) + 1.0)
+            extra = dict(dt=200.0)
         r = DistRank(rank, world, precision=prec, theta=0.5, **extra)
         r.upload(int(per * 2.5) + 1024, bodies.pos[a:z], bodies.vel[a:z], bodies.mass[a:z], a)
         if rad is not None:
@@ -126,7 +133,7 @@ def main():
         dt.distribute()
         dt.step(nsteps)
         idx, pos, vel, mass = dt.download()
-        np.savez(f"{out_prefix}.rank{rank}.npz", pos=pos, vel=vel, mass=mass, ids=idx)
+        np.savez(f"{out_prefix}.rank{rank}.npz", pos=pos, vel=vel, mass=mass, ids=idx, rebalances=dt.rebalances)
         r.close()
         dist.barrier()
         dist.destroy_process_group()

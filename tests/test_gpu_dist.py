@@ -260,6 +260,26 @@ def test_a_step_that_sends_most_bodies_elsewhere_gets_new_splitters_first(gpu):
     assert np.array_equal(idx2, idx) and np.array_equal(p2, p) and np.array_equal(v2, v) and np.array_equal(m2, m)
 
 
+def test_overflowing_step_over_torch_distributed(gpu, tmp_path):
+    """The scene of the test above with one rank per process (gloo, both on cuda:0): both processes read the same counts
+    and rooms out of one gather and turn back together; same bits as one engine."""
+    from tests.test_sharded_gloo import run_ranks
+    n = 40000
+    res = run_ranks(tmp_path, 2, ["tree", str(n), "3", "dist", "f32", "line"], timeout=240)
+    rng = np.random.default_rng(77)
+    pos = np.zeros((n, 3)); pos[:, 0] = rng.uniform(-3e4, 3e4, n)
+    vel = rng.normal(0, 1e-2, (n, 3)); mass = np.abs(rng.normal(1e4, 5e3, n)) + 1.0
+    with Engine(mode="tree", precision="f32", theta=0.5, dt=200.0, exact_sums=True) as e:
+        e.upload(pos, vel, mass)
+        e.step(3)
+        wp, wv, wm, wid = e.download()
+    assert all(int(r["rebalances"]) >= 1 for r in res)
+    idx = np.concatenate([r["ids"] for r in res]); order = np.argsort(idx)
+    assert np.array_equal(idx[order], wid)
+    for key, want in (("pos", wp), ("vel", wv), ("mass", wm)):
+        assert np.array_equal(np.concatenate([r[key] for r in res])[order], want)
+
+
 def test_new_splitters_during_a_run_change_nothing_but_the_owners(gpu):
     """Splitters are chosen anew whenever a rank holds too many bodies (forced here before every step): bodies change
     owner wholesale, the trajectories stay those of one engine."""

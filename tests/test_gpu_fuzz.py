@@ -83,9 +83,11 @@ def test_random_scenes_on_several_shards_equal_one_shard(gpu, block):
     """One engine handle driving 2..5 shards (all on this GPU; nbe_config.num_devices) against a one-shard engine on
     the same random scenes: tree mode bit for bit in every precision (also with the per-wave walk and the reference's
     own arithmetic), the direct sum to the rounding of a differently split source range."""
-    for s in range(9000 + 12 * block, 9000 + 12 * (block + 1)):
+    import os
+    per = int(os.environ.get("NBODY_FUZZ_SEEDS", "12"))
+    for s in range(9000 + per * block, 9000 + per * (block + 1)):
         rng = np.random.default_rng(s)
-        kind, pos, vel, mass, rad = scene(rng)
+        kind, pos, vel, mass, rad = scene(rng, int(os.environ.get("NBODY_FUZZ_SCALE", "1")))
         n = len(mass)
         mode = rng.choice(["direct", "tree"])
         precision = str(rng.choice(["f32", "mixed", "f64"]))
