@@ -444,7 +444,8 @@ static int collide_begin_t(nbe_engine* e, const void* force_pos)
     const double lox = e->cfg.bound_center[0] - 0.5 * W, loy = e->cfg.bound_center[1] - 0.5 * W,
                  loz = e->cfg.bound_center[2] - 0.5 * W;
     if (n == 0) {                                     // (a rank of the distributed tree may hold no body at all)
-        for (int k = 0; k < 4; k++) w.total_host[k] = 0;
+        if (w.total_host)                             // (no workspace yet: nothing was ever uploaded)
+            for (int k = 0; k < 4; k++) w.total_host[k] = 0;
         w.begun = true;
         return NBE_OK;
     }

@@ -688,6 +688,8 @@ int multi_dist_download(nbe_engine* e, double* pos, double* vel, double* mass, u
     MultiState* m = e->multi;
     DistMulti* d = m->dist;
     const size_t G = m->subs.size();
+    if (n_alive_out) *n_alive_out = 0;
+    if (d->capacity.size() != G) return NBE_OK;       // nothing uploaded yet
     std::vector<std::vector<uint64_t>> idx(G);
     std::vector<std::vector<double>> p(G), v(G), ms(G);
     std::vector<size_t> cnt(G, 0);
@@ -722,7 +724,7 @@ int multi_dist_get_radius(nbe_engine* e, double* radius, size_t* n_alive_out)
     const size_t G = m->subs.size();
     if (!e->cfg.collisions) { nbe_set_error("nbe_get_radius needs an engine created with collisions on"); return NBE_E_INVALID; }
     if (n_alive_out) *n_alive_out = 0;
-    if (e->n == 0) return NBE_OK;
+    if (e->n == 0 || d->capacity.size() != G) return NBE_OK;
     std::vector<std::vector<uint64_t>> idx(G);
     std::vector<std::vector<double>> rad(G);
     std::vector<size_t> cnt(G, 0);
@@ -820,6 +822,9 @@ int multi_set_radius(nbe_engine* e, const double* radius)
         // may grow to (sixteen times the largest given, at least 32 m): the splitters are then chosen anew, aligned for it
         DistMulti* d = m->dist;
         const size_t G = m->subs.size(), n = d->n_total, per = (n + G - 1) / G;
+        if (!e->cfg.collisions) { nbe_set_error("nbe_set_radius needs an engine created with collisions on"); return NBE_E_INVALID; }
+        if (n > 0 && !radius) { nbe_set_error("radius is NULL"); return NBE_E_INVALID; }
+        if (d->capacity.size() != G) return NBE_OK;      // nothing uploaded yet
         if (m->subs[0]->stats.steps != 0 || d->prepared) { nbe_set_error("with distributed = 1, nbe_set_radius comes right after nbe_upload"); return NBE_E_INVALID; }
         double cap = 2.0;
         for (size_t i = 0; i < n; i++) {
