@@ -132,10 +132,11 @@ def test_random_scenes_on_the_distributed_tree_equal_one_engine(gpu, block):
         precision = str(rng.choice(["f32", "mixed", "f64"]))
         shards = int(rng.integers(2, 7)); nsteps = int(rng.choice([1, 3, 6]))
         theta = float(rng.choice([0.3, 0.6, 1.0]))
-        tag = f"seed {s}: {kind} n={n} {precision} shards={shards} steps={nsteps} theta={theta}"
+        extra = run_params(rng)
+        tag = f"seed {s}: {kind} n={n} {precision} shards={shards} steps={nsteps} theta={theta} {extra}"
         out = []
         for kw in (dict(exact_sums=True), dict(devices=[0] * shards, distributed=True)):
-            with Engine(mode="tree", precision=precision, theta=theta, dt=200.0, **kw) as e:
+            with Engine(mode="tree", precision=precision, theta=theta, dt=200.0, **kw, **extra) as e:
                 e.upload(pos, vel, mass)
                 e.step(nsteps)
                 out.append(e.download() + (e.stats().n_alive,))
@@ -177,11 +178,12 @@ def test_random_scenes_with_collisions_on_the_distributed_tree_equal_one_engine(
         precision = str(rng.choice(["f32", "f64"]))
         shards = int(rng.integers(2, 7)); nsteps = int(rng.choice([1, 3, 6]))
         theta = float(rng.choice([0.3, 0.6, 1.0]))
-        tag = f"seed {s}: {kind} n={n} {precision} shards={shards} steps={nsteps} theta={theta}"
+        extra = run_params(rng)
+        tag = f"seed {s}: {kind} n={n} {precision} shards={shards} steps={nsteps} theta={theta} {extra}"
         out = []
         try:
             for kw in (dict(exact_sums=True), dict(devices=[0] * shards, distributed=True)):
-                with Engine(mode="tree", precision=precision, theta=theta, dt=200.0, collisions=True, **kw) as e:
+                with Engine(mode="tree", precision=precision, theta=theta, dt=200.0, collisions=True, **kw, **extra) as e:
                     e.upload(pos, vel, mass)
                     if n:
                         e.set_radius(rad)
@@ -198,6 +200,21 @@ def test_random_scenes_with_collisions_on_the_distributed_tree_equal_one_engine(
             assert np.array_equal(a, b), tag
         merges += out[0][5]
     assert merges > 20, merges                  # the scenes of a block do collide
+
+
+def run_params(rng):
+    """Run-time parameters beside the defaults (main.go:73-76): softening, another bound (offset, wider, an edge that is no
+    power of two), another G."""
+    kw = {}
+    if rng.random() < 0.3:
+        kw["eps"] = float(rng.choice([1.0, 50.0]))
+    if rng.random() < 0.3:
+        kw["bound_center"] = [float(v) for v in rng.uniform(-2e3, 2e3, 3)]
+    if rng.random() < 0.3:
+        kw["bound_width"] = float(rng.choice([131072.0, 1e5, 70000.0]))
+    if rng.random() < 0.2:
+        kw["G"] = 1e-10
+    return kw
 
 
 def _frame_sink(store):
@@ -249,8 +266,8 @@ def test_random_call_sequences_agree_between_engine_kinds(gpu, block):
             control, tol = dict(exact_sums=True), 0
         else:
             subject, control, tol = dict(devices=[0] * shards), {}, (1e-4 if precision == "f32" else 1e-10)
-        tag0 = f"seed {s}: {mode} {precision} collide={collide} theta={theta} {subject}"
-        kw = dict(mode=mode, precision=precision, theta=theta, dt=200.0, collisions=collide)
+        kw = dict(mode=mode, precision=precision, theta=theta, dt=200.0, collisions=collide, **run_params(rng))
+        tag0 = f"seed {s}: {subject} {kw}"
         engines = [Engine(**control, **kw), Engine(**subject, **kw)]
         frames = [[], []]
         streaming = False
