@@ -19,6 +19,7 @@
 #include "tree_sums.h"
 
 #include <cmath>
+#include <cstdlib>
 
 // tw.counters[COUNTER_SORTED_ALIVE]: live bodies found by the last key sort; becomes counters[0] when the state is
 // reordered (permute_kernel)
@@ -26,7 +27,7 @@
 __device__ __forceinline__ unsigned xcd_contiguous_block(void);
 
 #define SORT_KPT 8                     // keys per thread
-#define SORT_TILE (256 * SORT_KPT)     // keys per workgroup
+#define SORT_TILE (256 * SORT_KPT)     // keys per workgroup of the smallest kind (sizes the table of digit counts)
 #define SCAN_TILE 2048                 // elements per workgroup in the device-wide scan (256 threads x 8)
 
 // ---- device-wide exclusive scan of uint32 -------------------------------------------------------------
@@ -56,6 +57,29 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* total)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t inc = wave_incl_scan(v);
     if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        uint32_t s = wsum[w];
+        if (w < wave) base += s;
+        tot += s;
+    }
+    __syncthreads();
+    *total = tot;
+    return base + inc - v;
+}
+
+// The same for the 256 digit owners (threads 0..255) of a workgroup of T >= 256 threads: the other threads pass 0, join
+// the barriers and get nothing of use back.
+template <int T>
+__device__ __forceinline__ uint32_t block_excl_scan_digits(uint32_t v, uint32_t* total)
+{
+    if constexpr (T == 256) return block_excl_scan(v, total);
+    __shared__ uint32_t wsum[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t inc = wave_incl_scan(v);
+    if (lane == 63 && wave < 4) wsum[wave] = inc;
     __syncthreads();
     uint32_t base = 0, tot = 0;
 #pragma unroll
@@ -196,19 +220,19 @@ static int device_exclusive_scan(nbe_engine* e, const uint32_t* in, uint32_t* ou
 // A workgroup handles one tile of the radix sort and also counts the tile's lowest digits (the histogram of the first
 // pass), while the keys are still in registers; the first scatter pass takes a body's index from its position, so no
 // index array is written here.  The number of live bodies falls out of the sort's last pass (radix_scatter_kernel).
-template <typename R4>
-__global__ __launch_bounds__(256) void keys_kernel(const R4* __restrict__ posm, int n, double lox, double loy, double loz,
-                                                   double width, uint64_t* __restrict__ keys, int nblocks,
-                                                   uint32_t* __restrict__ block_hist, int by_xcd)
+template <typename R4, int T>
+__global__ __launch_bounds__(T) void keys_kernel(const R4* __restrict__ posm, int n, double lox, double loy, double loz,
+                                                 double width, uint64_t* __restrict__ keys, int nblocks,
+                                                 uint32_t* __restrict__ block_hist, int by_xcd)
 {
     __shared__ uint32_t h[256];
-    h[threadIdx.x] = 0;
+    if (threadIdx.x < 256) h[threadIdx.x] = 0;
     __syncthreads();
     const int tile = by_xcd ? (int)xcd_contiguous_block() : (int)blockIdx.x;
-    const int base = tile * SORT_TILE;
+    const int base = tile * (T * SORT_KPT);
 #pragma unroll
     for (int k = 0; k < SORT_KPT; k++) {
-        const int i = base + k * 256 + threadIdx.x;
+        const int i = base + k * T + threadIdx.x;
         if (i < n) {
             const R4 p = posm[i];
             const uint64_t key = body_key((double)p.x, (double)p.y, (double)p.z, lox, loy, loz, width);
@@ -217,53 +241,55 @@ __global__ __launch_bounds__(256) void keys_kernel(const R4* __restrict__ posm, 
         }
     }
     __syncthreads();
-    block_hist[(size_t)threadIdx.x * nblocks + tile] = h[threadIdx.x];
+    if (threadIdx.x < 256) block_hist[(size_t)threadIdx.x * nblocks + tile] = h[threadIdx.x];
 }
 
 // ---- LSD radix sort, 8-bit digits, (key, index) pairs ---------------------------------------------------------
-__global__ __launch_bounds__(256) void radix_hist_kernel(const uint64_t* __restrict__ keys, int n, int shift, int nblocks,
-                                                         uint32_t* __restrict__ block_hist, int by_xcd)
+template <int T>
+__global__ __launch_bounds__(T) void radix_hist_kernel(const uint64_t* __restrict__ keys, int n, int shift, int nblocks,
+                                                       uint32_t* __restrict__ block_hist, int by_xcd)
 {
     __shared__ uint32_t h[256];
-    h[threadIdx.x] = 0;
+    if (threadIdx.x < 256) h[threadIdx.x] = 0;
     __syncthreads();
     const int tile = by_xcd ? (int)xcd_contiguous_block() : (int)blockIdx.x;     // the XCD that will scatter this tile also counts it
-    const int base = tile * SORT_TILE;
+    const int base = tile * (T * SORT_KPT);
 #pragma unroll
     for (int k = 0; k < SORT_KPT; k++) {
-        int i = base + k * 256 + threadIdx.x;
+        int i = base + k * T + threadIdx.x;
         if (i < n) atomicAdd(&h[(uint32_t)(keys[i] >> shift) & 255u], 1u);
     }
     __syncthreads();
-    block_hist[(size_t)threadIdx.x * nblocks + tile] = h[threadIdx.x];
+    if (threadIdx.x < 256) block_hist[(size_t)threadIdx.x * nblocks + tile] = h[threadIdx.x];
 }
 
 // Stable scatter.  Each wave owns a contiguous quarter of the tile and walks it 64 keys at a time; within a
 // round, lanes holding the same digit find each other with 8 ballots, and a per-wave digit counter in LDS
 // carries the running count across rounds.  The tile is then reordered in LDS and written out in runs.
-__global__ __launch_bounds__(256) void radix_scatter_kernel(const uint64_t* __restrict__ kin, const uint32_t* __restrict__ vin,
-                                                            uint64_t* __restrict__ kout, uint32_t* __restrict__ vout,
-                                                            const uint32_t* __restrict__ offsets,
-                                                            const uint32_t* __restrict__ totals, int n, int shift, int nblocks,
-                                                            int* __restrict__ alive_out, int by_xcd)
+template <int T>
+__global__ __launch_bounds__(T) void radix_scatter_kernel(const uint64_t* __restrict__ kin, const uint32_t* __restrict__ vin,
+                                                          uint64_t* __restrict__ kout, uint32_t* __restrict__ vout,
+                                                          const uint32_t* __restrict__ offsets,
+                                                          const uint32_t* __restrict__ totals, int n, int shift, int nblocks,
+                                                          int* __restrict__ alive_out, int by_xcd)
 {
-    __shared__ uint32_t wcount[4][256];
-    __shared__ uint32_t wbase[4][256];
+    constexpr int WAVES = T / 64, TILE = T * SORT_KPT;
+    __shared__ uint32_t wcount[WAVES][256];
+    __shared__ uint32_t wbase[WAVES][256];
     __shared__ uint32_t dbase[256], gdelta[256];
-    __shared__ uint64_t skey[SORT_TILE];
-    __shared__ uint32_t sval[SORT_TILE];
+    __shared__ uint64_t skey[TILE];
+    __shared__ uint32_t sval[TILE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // Neighbouring tiles write neighbouring slots of every digit's run: with the workgroups of one XCD on a contiguous
     // eighth of the tiles, the halves of a line meet in one L2 instead of being written back from two (16M bodies:
     // 159 -> 140 us per pass, and the histogram pass over the same tiles 53 -> 39 us).  Sorts of a few hundred tiles,
     // which fit the caches anyway, ran 5 % slower that way and keep the plain numbering.
     const int tile = by_xcd ? (int)xcd_contiguous_block() : (int)blockIdx.x;
-#pragma unroll
-    for (int w = 0; w < 4; w++) wcount[w][tid] = 0;
+    for (int w = tid; w < WAVES * 256; w += T) (&wcount[0][0])[w] = 0;
     __syncthreads();
 
     volatile uint32_t* wc = wcount[wave];
-    const int base = tile * SORT_TILE + wave * (SORT_TILE / 4);
+    const int base = tile * TILE + wave * (TILE / WAVES);
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     uint64_t k[SORT_KPT];
     uint32_t v[SORT_KPT], rank[SORT_KPT];
@@ -289,24 +315,28 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const uint64_t* __re
     __syncthreads();
     // Per digit: offsets of the four waves within the digit, the digit's count in this tile, and (after the
     // scan) the digit's first slot in the tile's digit-sorted order.
-    uint32_t dcount;
-    {
+    // (threads 0..255 own one digit each; in a wider workgroup the others only keep the barriers company)
+    const int dt = tid & 255;
+    uint32_t dcount = 0;
+    if (tid < 256) {
         uint32_t run = 0;
 #pragma unroll
-        for (int w = 0; w < 4; w++) { wbase[w][tid] = run; run += wcount[w][tid]; }
+        for (int w = 0; w < WAVES; w++) { wbase[w][tid] = run; run += wcount[w][tid]; }
         dcount = run;
     }
     {
         uint32_t tot;
-        const uint32_t dstart = block_excl_scan(dcount, &tot);     // contains the barriers that publish wbase
-        dbase[tid] = dstart;
+        const uint32_t dstart = block_excl_scan_digits<T>(dcount, &tot);     // contains the barriers that publish wbase
         // keys with a smaller digit anywhere + keys with this digit in earlier tiles = where this digit's run goes
         // in the output; minus its first slot in the tile: global = slot + gdelta
-        const uint32_t below = block_excl_scan(totals[tid], &tot);
-        gdelta[tid] = below + offsets[(size_t)tid * nblocks + tile] - dstart;
-        // Last pass (key bits 56..63): every live key (63 bits) has a digit below 255, the all-ones key of a body
-        // outside the bound has 255, so the keys below digit 255 are the live bodies.
-        if (alive_out && tile == 0 && tid == 255) *alive_out = (int)below;
+        const uint32_t below = block_excl_scan_digits<T>(tid < 256 ? totals[dt] : 0u, &tot);
+        if (tid < 256) {
+            dbase[tid] = dstart;
+            gdelta[tid] = below + offsets[(size_t)tid * nblocks + tile] - dstart;
+            // Last pass (key bits 56..63): every live key (63 bits) has a digit below 255, the all-ones key of a body
+            // outside the bound has 255, so the keys below digit 255 are the live bodies.
+            if (alive_out && tile == 0 && tid == 255) *alive_out = (int)below;
+        }
     }
     __syncthreads();
     // Stage the tile in digit-sorted order in LDS, then write it out with consecutive threads on consecutive
@@ -323,10 +353,10 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const uint64_t* __re
         }
     }
     __syncthreads();
-    const int tile_n = min(SORT_TILE, n - tile * SORT_TILE);
+    const int tile_n = min(TILE, n - tile * TILE);
 #pragma unroll
     for (int r = 0; r < SORT_KPT; r++) {
-        const int slot = r * 256 + tid;
+        const int slot = r * T + tid;
         if (slot < tile_n) {
             const uint64_t key = skey[slot];
             const uint32_t pos = (uint32_t)slot + gdelta[(uint32_t)(key >> shift) & 255u];
@@ -1300,6 +1330,32 @@ int tree_workspace_reserve(nbe_engine* e)
     return NBE_OK;
 }
 
+// Key generation and the eight radix passes with workgroups of T threads (tiles of 8 T keys).
+template <typename R4, int T>
+static int radix_passes_t(nbe_engine* e, const R4* force_pos, int n, double lox, double loy, double loz, double W)
+{
+    TreeWork& w = e->tw;
+    const int nblocks = (int)cdiv(n, T * SORT_KPT);
+    const int by_xcd = nblocks >= 2048 * 256 / T;
+    hipLaunchKernelGGL((keys_kernel<R4, T>), dim3(nblocks), dim3(T), 0, e->stream, force_pos, n, lox, loy, loz, W, w.keys[0],
+                       nblocks, w.block_hist, by_xcd);
+    NBE_HIP(hipGetLastError());
+    int in = 0;
+    for (int pass = 0; pass < 8; pass++) {
+        const int shift = pass * 8;
+        if (pass > 0)       // the key kernel has counted the digits of the first pass
+            hipLaunchKernelGGL((radix_hist_kernel<T>), dim3(nblocks), dim3(T), 0, e->stream, w.keys[in], n, shift, nblocks,
+                               w.block_hist, by_xcd);
+        hipLaunchKernelGGL(scan_rows_kernel, dim3(256), dim3(256), 0, e->stream, w.block_hist, nblocks, w.scan_tmp);
+        hipLaunchKernelGGL((radix_scatter_kernel<T>), dim3(nblocks), dim3(T), 0, e->stream, w.keys[in],
+                           pass > 0 ? w.sidx[in] : (const uint32_t*)nullptr, w.keys[in ^ 1], w.sidx[in ^ 1], w.block_hist,
+                           w.scan_tmp, n, shift, nblocks, pass == 7 ? w.counters + COUNTER_SORTED_ALIVE : (int*)nullptr, by_xcd);
+        NBE_HIP(hipGetLastError());
+        in ^= 1;
+    }
+    return NBE_OK;
+}
+
 // Keys of the current state and their sorted order (w.keys[0], w.sidx[0], live count): everything of the sort that
 // reads positions only.  The state itself is reordered afterwards, by sort_and_build_t.
 template <typename R4>
@@ -1320,25 +1376,14 @@ static int sort_keys_t(nbe_engine* e)
         return NBE_OK;
     }
     // 63-bit keys plus the all-ones dead key: 8 passes of 8 bits, ending back in buffer 0.
-    const int nblocks = (int)cdiv(n, SORT_TILE);
-    const int by_xcd = nblocks >= 2048;
-    hipLaunchKernelGGL((keys_kernel<R4>), dim3(nblocks), dim3(256), 0, e->stream, force_pos, n, lox, loy, loz, W, w.keys[0],
-                       nblocks, w.block_hist, by_xcd);
-    NBE_HIP(hipGetLastError());
-    int in = 0;
-    for (int pass = 0; pass < 8; pass++) {
-        const int shift = pass * 8;
-        if (pass > 0)       // the key kernel has counted the digits of the first pass
-            hipLaunchKernelGGL(radix_hist_kernel, dim3(nblocks), dim3(256), 0, e->stream, w.keys[in], n, shift, nblocks,
-                               w.block_hist, by_xcd);
-        hipLaunchKernelGGL(scan_rows_kernel, dim3(256), dim3(256), 0, e->stream, w.block_hist, nblocks, w.scan_tmp);
-        hipLaunchKernelGGL(radix_scatter_kernel, dim3(nblocks), dim3(256), 0, e->stream, w.keys[in],
-                           pass > 0 ? w.sidx[in] : (const uint32_t*)nullptr, w.keys[in ^ 1], w.sidx[in ^ 1], w.block_hist,
-                           w.scan_tmp, n, shift, nblocks, pass == 7 ? w.counters + COUNTER_SORTED_ALIVE : (int*)nullptr, by_xcd);
-        NBE_HIP(hipGetLastError());
-        in ^= 1;
-    }
-    return NBE_OK;
+    // Workgroups of 512 threads, tiles of 4,096 keys: a digit's run in a tile is 16 keys on average instead of 8, half as many
+    // rows for the scan.  Sort phase at 1M / 2M / 4M / 16M bodies: 0.187 / 0.262 / 0.413 / 1.76 ms against 0.196 / 0.290 /
+    // 0.420 / 1.88 with 256 threads and 0.229 / 0.263 / 0.426 / 1.74 with 1,024 (one workgroup per CU then).
+    // NBODY_SORT_THREADS = 256, 512 or 1024 picks one, for measurements.
+    static const int threads_env = getenv("NBODY_SORT_THREADS") ? atoi(getenv("NBODY_SORT_THREADS")) : 0;
+    if (threads_env == 256) return radix_passes_t<R4, 256>(e, force_pos, n, lox, loy, loz, W);
+    if (threads_env == 1024) return radix_passes_t<R4, 1024>(e, force_pos, n, lox, loy, loz, W);
+    return radix_passes_t<R4, 512>(e, force_pos, n, lox, loy, loz, W);
 }
 
 template <typename R4, typename S4, typename NodeT, int SUMS>
