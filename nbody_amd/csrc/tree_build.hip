@@ -263,7 +263,7 @@ __global__ __launch_bounds__(T) void radix_hist_kernel(const uint64_t* __restric
     if (threadIdx.x < 256) block_hist[(size_t)threadIdx.x * nblocks + tile] = h[threadIdx.x];
 }
 
-// Stable scatter.  Each wave owns a contiguous quarter of the tile and walks it 64 keys at a time; within a
+// Stable scatter.  Each wave owns a contiguous share of the tile (512 keys) and walks it 64 keys at a time; within a
 // round, lanes holding the same digit find each other with 8 ballots, and a per-wave digit counter in LDS
 // carries the running count across rounds.  The tile is then reordered in LDS and written out in runs.
 template <int T>
