@@ -173,7 +173,7 @@ def test_a_rank_that_runs_out_of_slots_says_so(gpu):
                 r.close()
 
 
-@pytest.mark.parametrize("world,precision", [(2, "f32"), (3, "f64")])
+@pytest.mark.parametrize("world,precision", [(2, "f32"), (3, "f64"), (8, "f32")])
 def test_one_process_per_rank_over_torch_distributed(gpu, tmp_path, world, precision):
     """The same stepper with one rank per process and the exchanges as torch.distributed collectives (gloo here, all
     ranks on cuda:0; "nccl" = RCCL takes the same path with device buffers): together the ranks hold what one engine
