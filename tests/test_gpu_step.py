@@ -104,6 +104,25 @@ def test_two_ranks_on_one_gpu_match_single_engine(gpu, tmp_path, mode, precision
         assert np.abs(res[0]["vel"] - v).max() <= 1e-5 * np.abs(v).max()
 
 
+@pytest.mark.parametrize("mode,precision,n", [("tree", "f32", 8192), ("tree", "mixed", 30001), ("direct", "f32", 20000)])
+def test_eight_ranks_on_one_gpu_match_single_engine(gpu, tmp_path, mode, precision, n):
+    """The same with world_size 8, the number of ranks of the full node (8,192 bodies split into the two ranges per rank of
+    the stepper's overlapped exchange)."""
+    world = 8
+    res = run_ranks(tmp_path, world, [mode, str(n), "3", "gpu", precision] + (["split"] if n % (512 * world) == 0 else []), timeout=300)
+    for r in res[1:]:
+        assert np.array_equal(res[0]["pos"], r["pos"]) and np.array_equal(res[0]["vel"], r["vel"])
+    b = physics.makebodies(n - 2, seed=11)
+    with Engine(mode=mode, precision=precision, theta=0.5) as e:
+        e.upload(b.pos, b.vel, b.mass)
+        e.step(3)
+        p, v, m, ids = e.download()
+    if mode == "tree":
+        assert np.array_equal(res[0]["pos"], p) and np.array_equal(res[0]["vel"], v)
+    else:
+        assert np.abs(res[0]["pos"] - p).max() <= 1e-6 * np.abs(p).max()
+
+
 @pytest.mark.parametrize("mode,precision", [("direct", "f32"), ("tree", "f32"), ("tree", "mixed"), ("direct", "f64")])
 def test_frame_stream_delivers_the_state_before_each_step(gpu, mode, precision):
     """main.go:90-101: a copy of the live bodies goes to the output workers before every iteration.  The streamed
