@@ -171,12 +171,21 @@ def main():
         log(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}; using WORLD_SIZE")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    # NBODY_BENCH_REHEARSE=gloo: every rank on GPU 0 and the collectives over gloo (RCCL refuses two ranks on one GPU), to
+    # walk the code of an N-rank run on a one-GPU box; the figures of such a run mean nothing
+    rehearse = os.environ.get("NBODY_BENCH_REHEARSE") == "gloo"
+    if rehearse:
+        local = 0
     torch.cuda.set_device(local)
+    red_dev = "cpu" if rehearse else "cuda"                        # where the small reductions of timings live
     force_dist = os.environ.get("NBODY_BENCH_FORCE_DIST") == "1"   # rehearse the RCCL path with a single rank
     if world > 1 or force_dist:
         if force_dist and "MASTER_ADDR" not in os.environ:
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     def sync():
         torch.cuda.synchronize()
@@ -200,7 +209,7 @@ def main():
             step_fn = eng.step
         sec = timed_steps(step_fn, sync, barrier, warmup, steps)
         if world > 1:
-            t = torch.tensor([sec], device="cuda", dtype=torch.float64)
+            t = torch.tensor([sec], device=red_dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             sec = float(t.item())
         return eng, sec
@@ -218,7 +227,7 @@ def main():
     else:
         full = st.interactions
         if world > 1:
-            t = torch.tensor([float(full)], device="cuda", dtype=torch.float64)
+            t = torch.tensor([float(full)], device=red_dev, dtype=torch.float64)
             dist.all_reduce(t)
             full = float(t.item())
         inter_per_step = full
@@ -247,7 +256,7 @@ def main():
             for k, v in prof.step_profiled().items():
                 acc[k] = acc.get(k, 0.0) + v / 2
         if world > 1:
-            t = torch.tensor([acc[k] for k in sorted(acc)], device="cuda", dtype=torch.float64)
+            t = torch.tensor([acc[k] for k in sorted(acc)], device=red_dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             acc = {k: float(v) for k, v in zip(sorted(acc), t.tolist())}
         extra["headline_sharded_phase_ms"] = acc
@@ -263,7 +272,7 @@ def main():
         kms = e2.time_force_kernel(3)
         s_inter = e2.stats().interactions
         if world > 1:
-            t = torch.tensor([float(s_inter)], device="cuda", dtype=torch.float64)
+            t = torch.tensor([float(s_inter)], device=red_dev, dtype=torch.float64)
             dist.all_reduce(t)
             s_inter = float(t.item())
         key = "bh_theta0.5_fp32_plummer_1M" if other == "tree" else "direct_fp32_plummer_1M"
@@ -290,7 +299,7 @@ def main():
         kms3 = e3.time_force_kernel(2)          # also counts this rank's force evaluations
         i3 = float(e3.stats().interactions)
         if world > 1:
-            t = torch.tensor([i3], device="cuda", dtype=torch.float64)
+            t = torch.tensor([i3], device=red_dev, dtype=torch.float64)
             dist.all_reduce(t)
             i3 = float(t.item())
         extra["bh_theta0.5_fp32_plummer_16M"] = {"steps_per_s": 5 / s3, "ms_per_step": 1e3 * s3 / 5,
@@ -316,7 +325,7 @@ def main():
                 for k, v in prof.step_profiled().items():
                     acc[k] = acc.get(k, 0.0) + v / 3
             if world > 1:
-                t = torch.tensor([acc[k] for k in sorted(acc)], device="cuda", dtype=torch.float64)
+                t = torch.tensor([acc[k] for k in sorted(acc)], device=red_dev, dtype=torch.float64)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 acc = {k: float(v) for k, v in zip(sorted(acc), t.tolist())}
             extra["bh_theta0.5_fp32_plummer_16M"]["sharded_phase_ms"] = acc
@@ -348,7 +357,7 @@ def main():
         st5 = ShardedStepper(EngineShard(e5, device_index=local), always_gather=force_dist)
         sec5 = timed_steps(st5.step, sync, barrier, 2, 98)
         if world > 1:
-            t = torch.tensor([sec5], device="cuda", dtype=torch.float64)
+            t = torch.tensor([sec5], device=red_dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             sec5 = float(t.item())
         sync()
@@ -552,11 +561,11 @@ def main():
             acc = {k: float(np.median([t.get(k, 0.0) for t in runs])) for k in keys}
             live = float(ranks[0].engine.stats().n_alive)
             if world > 1:
-                t = torch.tensor([sec] + [acc[k] for k in sorted(acc)], device="cuda", dtype=torch.float64)
+                t = torch.tensor([sec] + [acc[k] for k in sorted(acc)], device=red_dev, dtype=torch.float64)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 sec = float(t[0].item())
                 acc = {k: float(v) for k, v in zip(sorted(acc), t[1:].tolist())}
-                t = torch.tensor([live, -live], device="cuda", dtype=torch.float64)
+                t = torch.tensor([live, -live], device=red_dev, dtype=torch.float64)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 live = [float(t[0].item()), -float(t[1].item())]
             ref = one_gpu_reference("bh_theta0.5_fp32_plummer_16M" if "plummer" in key else "galaxy_pair_2x8M_bh_mixed_eps1")
