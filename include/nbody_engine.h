@@ -73,7 +73,7 @@ typedef struct {
  * With cfg.distributed = 1 (tree mode, per-body criterion, no reference_quirks; collisions allowed) the GPUs do not replicate the
  * bodies: the engine runs the key-range-distributed tree described at nbe_dist_upload below on its GPUs, one host thread per
  * GPU, with peer copies for the exchanges.  nbe_upload, nbe_step, nbe_download, nbe_stats, nbe_energy (tree potential),
- * nbe_set_radius (right after nbe_upload), nbe_get_radius, nbe_sync and the frame stream, radii included, work (no GPU
+ * nbe_set_radius (right after nbe_upload), nbe_get_radius, nbe_accel, nbe_sync and the frame stream, radii included, work (no GPU
  * holds all bodies: every GPU snapshots its own before the step and sends
  * them into its stretch of the frame's pinned buffer on a stream of its own; the rows of a frame are in key order);
  * results equal those of one GPU with cell_sums = NBE_SUMS_EXACT bit for bit in fp32 and fp64; the other calls are refused. */
@@ -336,6 +336,9 @@ int nbe_dist_advance(nbe_engine *e);
  * phi_i summed over the nodes body i's walk accepts in the assembled array (all bodies of the run, softened by eps).  The
  * run's totals are the sums over the ranks.  Synchronises. */
 int nbe_dist_energy(nbe_engine *e, double *kinetic, double *potential, double momentum[3]);
+/* This rank's share of nbe_accel, between nbe_dist_assemble and nbe_dist_advance: the accelerations f/m of its bodies
+ * (tree.go:202-240 over the assembled array) with their run-wide indices (index may be NULL).  Synchronises. */
+int nbe_dist_accel(nbe_engine *e, uint64_t *index, double *acc_xyz, size_t *count);
 /* The rank's live bodies: run-wide index, position, velocity, mass (any pointer may be NULL). */
 int nbe_dist_download(nbe_engine *e, uint64_t *index, double *pos_xyz, double *vel_xyz, double *mass, size_t *count);
 /* Collisions on: the radii of the rank's live bodies (physics.go:94; merged bodies have grown, physics.go:139) with their

@@ -1384,6 +1384,46 @@ extern "C" int nbe_dist_energy(nbe_engine* e, double* ke, double* pe, double mom
     return NBE_OK;
 }
 
+// This rank's share of nbe_accel: the accelerations of its bodies from the assembled tree (the instrumented pass that
+// nbe_dist_energy runs too; it also counts the rank's force evaluations), with their run-wide indices.
+static int accel_t(nbe_engine* e, uint64_t* index, double* acc, size_t* count)
+{
+    DistState* d = e->dist;
+    *count = 0;
+    const size_t k = d->live_hi;
+    if (k == 0) return NBE_OK;
+    void* nodes = e->tw.nodes;
+    int* counters = e->tw.counters;
+    e->tw.nodes = d->let_nodes;
+    e->tw.counters = d->let_counters;
+    const int rc = tree_forces(e, e->cur, 0, e->n, false, true, e->cur ^ 1);
+    e->tw.nodes = nodes;
+    e->tw.counters = counters;
+    NBE_TRY(rc);
+    std::vector<uint32_t> ho(k);
+    std::vector<double> ha;
+    std::vector<float> fa;
+    NBE_HIP(hipMemcpyAsync(ho.data(), e->orig[e->orig_cur], k * 4, hipMemcpyDeviceToHost, e->stream));
+    if (e->state64) { ha.resize(4 * k); NBE_HIP(hipMemcpyAsync(ha.data(), e->acc, k * 32, hipMemcpyDeviceToHost, e->stream)); }
+    else { fa.resize(4 * k); NBE_HIP(hipMemcpyAsync(fa.data(), e->acc, k * 16, hipMemcpyDeviceToHost, e->stream)); }
+    NBE_HIP(hipStreamSynchronize(e->stream));
+    for (size_t i = 0; i < k; i++) {
+        for (int c = 0; c < 3; c++) acc[3 * i + c] = e->state64 ? ha[4 * i + c] : (double)fa[4 * i + c];
+        if (index) index[i] = ho[i];
+    }
+    *count = k;
+    return NBE_OK;
+}
+
+extern "C" int nbe_dist_accel(nbe_engine* e, uint64_t* index, double* acc_xyz, size_t* count)
+{
+    NBE_TRY(check_dist(e, "nbe_dist_accel"));
+    if (!acc_xyz || !count) { nbe_set_error("NULL argument"); return NBE_E_INVALID; }
+    if (!e->dist->assembled) { nbe_set_error("nbe_dist_accel needs the assembled tree (between nbe_dist_assemble and nbe_dist_advance)"); return NBE_E_INVALID; }
+    try { return accel_t(e, index, acc_xyz, count); }
+    catch (const std::bad_alloc&) { nbe_set_error("out of host memory"); return NBE_E_NOMEM; }
+}
+
 static int download_t(nbe_engine* e, uint64_t* index, double* pos, double* vel, double* mass, double* radius, size_t* count)
 {
     DistState* d = e->dist;

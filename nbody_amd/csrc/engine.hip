@@ -815,7 +815,7 @@ extern "C" int nbe_get_radius(nbe_engine* e, double* radius, size_t* n_alive_out
 }
 extern "C" int nbe_accel(nbe_engine* e, double* acc_xyz, uint8_t* alive_out)
 {
-    NBE_NOT_DISTRIBUTED(e, "nbe_accel");
+    if (e && multi_is_distributed(e)) { NBE_GUARDED(multi_dist_accel(e, acc_xyz, alive_out)) }
     NBE_GUARDED(accel_impl(NBE_FIRST(e), acc_xyz, alive_out))
 }
 extern "C" int nbe_tree_nodes(nbe_engine* e, double* out, size_t cap, size_t* count)

@@ -219,6 +219,7 @@ bool multi_is_distributed(const nbe_engine* e);  // cfg.distributed: no GPU hold
 int multi_dist_download(nbe_engine* e, double* pos, double* vel, double* mass, uint64_t* id, size_t* n_alive_out);
 int multi_dist_energy(nbe_engine* e, double* ke, double* pe, double mom[3]);
 int multi_dist_get_radius(nbe_engine* e, double* radius, size_t* n_alive_out);
+int multi_dist_accel(nbe_engine* e, double* acc_xyz, uint8_t* alive_out);
 int multi_dist_stats(nbe_engine* e, nbe_stats_t* out);
 int multi_dist_frames_begin(nbe_engine* e, int every, int slots, int first_frame, nbe_frame_cb cb, void* user);
 int multi_dist_frames_end(nbe_engine* e);

@@ -716,6 +716,38 @@ int multi_dist_download(nbe_engine* e, double* pos, double* vel, double* mass, u
     return NBE_OK;
 }
 
+// nbe_accel on the distributed tree: every GPU's accelerations of its own bodies, put in upload order; bodies that are
+// gone (outside the bound, absorbed) get zeros and alive = 0.
+int multi_dist_accel(nbe_engine* e, double* acc_xyz, uint8_t* alive_out)
+{
+    MultiState* m = e->multi;
+    DistMulti* d = m->dist;
+    const size_t G = m->subs.size(), n = d->n_total;
+    if (n == 0 || d->capacity.size() != G) return NBE_OK;
+    if (!acc_xyz) { nbe_set_error("acc_xyz is NULL"); return NBE_E_INVALID; }
+    if (!d->prepared) NBE_TRY(dist_prepare(e));
+    std::vector<std::vector<uint64_t>> idx(G);
+    std::vector<std::vector<double>> acc(G);
+    std::vector<size_t> cnt(G, 0);
+    NBE_TRY(d->pool.run([&](int r) -> int {
+        const size_t cap = d->capacity[(size_t)r];
+        idx[(size_t)r].resize(cap); acc[(size_t)r].resize(3 * cap);
+        return nbe_dist_accel(m->subs[(size_t)r], idx[(size_t)r].data(), acc[(size_t)r].data(), &cnt[(size_t)r]);
+    }));
+    for (size_t u = 0; u < n; u++) {
+        acc_xyz[3 * u] = acc_xyz[3 * u + 1] = acc_xyz[3 * u + 2] = 0.0;
+        if (alive_out) alive_out[u] = 0;
+    }
+    for (size_t r = 0; r < G; r++)
+        for (size_t k = 0; k < cnt[r]; k++) {
+            const uint64_t u = idx[r][k];
+            if (u >= n) continue;
+            for (int c = 0; c < 3; c++) acc_xyz[3 * u + (size_t)c] = acc[r][3 * k + (size_t)c];
+            if (alive_out) alive_out[u] = 1;
+        }
+    return NBE_OK;
+}
+
 // Radii of the survivors in upload order (the order of multi_dist_download).
 int multi_dist_get_radius(nbe_engine* e, double* radius, size_t* n_alive_out)
 {

@@ -61,6 +61,7 @@ def _declare(lib):
                                     C.POINTER(C.c_int64)]
     lib.nbe_dist_download.argtypes = [vp, u64p, dp, dp, dp, C.POINTER(C.c_size_t)]
     lib.nbe_dist_get_radius.argtypes = [vp, u64p, dp, C.POINTER(C.c_size_t)]
+    lib.nbe_dist_accel.argtypes = [vp, u64p, dp, C.POINTER(C.c_size_t)]
     for name in DIST_EXPORTS:
         getattr(lib, name).restype = C.c_int
     _declared = True
@@ -89,7 +90,7 @@ def layout(all_frags, sizes):
 
 DIST_EXPORTS = ["nbe_dist_layout", "nbe_dist_energy", "nbe_dist_set_total_mass", "nbe_dist_set_radius", "nbe_dist_upload", "nbe_dist_sample_keys", "nbe_dist_set_splitters", "nbe_dist_buffers", "nbe_dist_classify",
                 "nbe_dist_receive", "nbe_dist_build", "nbe_dist_export", "nbe_dist_assemble", "nbe_dist_advance",
-                "nbe_dist_download", "nbe_dist_get_radius", "nbe_dist_room", "nbe_dist_unclassify"]
+                "nbe_dist_download", "nbe_dist_get_radius", "nbe_dist_room", "nbe_dist_unclassify", "nbe_dist_accel"]
 
 
 def _dp(a):
@@ -240,6 +241,14 @@ class DistRank:
                                                 C.byref(k)))
         k = k.value
         return idx[:k], pos[:k], vel[:k], mass[:k]
+
+    def accel(self):
+        """(run-wide indices, accelerations[k, 3]) of this rank's bodies; needs the assembled tree."""
+        n = self.capacity
+        idx = np.zeros(n, dtype=np.uint64); acc = np.zeros((n, 3))
+        k = C.c_size_t(0)
+        self._check(self._lib.nbe_dist_accel(self._h, idx.ctypes.data_as(C.POINTER(C.c_uint64)), _dp(acc), C.byref(k)))
+        return idx[:k.value], acc[:k.value]
 
     def get_radius(self):
         """Collisions on: (run-wide indices, radii) of this rank's live bodies, in the order of download()."""

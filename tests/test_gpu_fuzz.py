@@ -278,7 +278,7 @@ def test_random_call_sequences_agree_between_engine_kinds(gpu, block):
         streaming = False
         log = []
         try:
-            ops = ["upload"] + [str(o) for o in rng.choice(["upload", "step", "step", "step", "download", "stats", "radius", "frames", "energy"],
+            ops = ["upload"] + [str(o) for o in rng.choice(["upload", "step", "step", "step", "download", "stats", "radius", "frames", "energy", "accel"],
                                                            size=int(rng.integers(4, 10)))] + ["download", "stats"]
             n = 0
             for op in ops:
@@ -335,6 +335,10 @@ def test_random_call_sequences_agree_between_engine_kinds(gpu, block):
                     ktol = max(1e-12, tol)
                     assert abs(ka - kb) <= ktol * abs(ka) and abs(pa - pb) <= ptol * abs(pa), f"{tag0} {log}: {ka} {kb} {pa} {pb}"
                     assert np.abs(ma - mb).max() <= ktol * (np.abs(mass).max() * np.abs(vel).max() * n + 1e-300), f"{tag0} {log}"
+                elif op == "accel" and n and mode == "tree":
+                    log.append("accel")
+                    (aa, la), (ab, lb) = (e.accel() for e in engines)
+                    assert np.array_equal(la, lb) and _same(aa, ab, tol), f"{tag0} {log}"
                 elif op == "radius" and collide:
                     log.append("radius")
                     a, b = (e.get_radius() for e in engines)

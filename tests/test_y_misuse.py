@@ -73,7 +73,7 @@ def test_dist_rank_misuse(gpu):
         try:
             for k in range(int(rng.integers(3, 30))):
                 op = ["upload", "mass", "sample", "split"][k] if (k < 4 and world == 1) else str(rng.choice(["upload", "mass", "radius", "sample", "split", "classify", "room", "unclassify", "receive", "build",
-                                     "export", "assemble", "advance", "energy", "download", "get_radius"]))
+                                     "export", "assemble", "advance", "energy", "download", "get_radius", "accel"]))
                 log.append(op)
                 try:
                     if op == "upload":
@@ -95,6 +95,7 @@ def test_dist_rank_misuse(gpu):
                     elif op == "energy": r.energy()
                     elif op == "download": r.download()
                     elif op == "get_radius": r.get_radius()
+                    elif op == "accel": r.accel()
                     elif op == "export" and world == 1:
                         fr, bx, live = r.build()
                         r.export(fr, np.array([len(fr)], dtype=np.int32), [bx])
