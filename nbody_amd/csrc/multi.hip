@@ -8,6 +8,7 @@
 // next-state buffers.  All of it is queued on the engines' streams and ordered by events; the host never waits
 // inside a step.
 #include "engine_internal.h"
+#include <cstdlib>
 
 #include <algorithm>
 #include <cstring>
@@ -324,7 +325,11 @@ static int dist_upload(nbe_engine* e, size_t n, const double* pos, const double*
     d->n_total = n;
     d->ids.resize(n);
     for (size_t i = 0; i < n; i++) d->ids[i] = id ? id[i] : (uint64_t)i;
-    d->capacity.assign(G, per + per / 4 + 4096);     // room for a quarter more than an even share
+    // room for a quarter more than an even share; NBODY_DIST_HEADROOM = h (1.25 .. number of GPUs) gives h even shares
+    // instead, for scenes that cannot be shared out evenly (with h = number of GPUs any distribution fits)
+    double headroom = 1.25;
+    if (const char* env = getenv("NBODY_DIST_HEADROOM")) headroom = std::min(std::max(atof(env), 1.25), (double)G);
+    d->capacity.assign(G, (size_t)((double)per * headroom) + 4096);
     d->bufs.assign(G, nbe_dist_buffers_t{});
     double total_mass = 0.0;                         // fixes the quantum of the exact cell sums, alike on every GPU
     for (size_t i = 0; i < n; i++) total_mass += mass[i];
@@ -369,7 +374,7 @@ static int dist_prepare(nbe_engine* e)
         // step than the spare slots allow.  The leavers go back to their slots, new splitters are chosen from the bodies
         // as they are now, and the classification is done again.
         if (attempt == 1) {
-            nbe_set_error("the GPUs' capacities do not hold the bodies even with new splitters%s",
+            nbe_set_error("the GPUs' capacities do not hold the bodies even with new splitters (NBODY_DIST_HEADROOM, read at nbe_upload, gives every GPU more room)%s",
                           e->cfg.collisions ? " (with collisions on a splitter sits on the border of a cell at least four radius caps wide: "
                                               "the bodies may span too few such cells to be shared out evenly)" : "");
             return NBE_E_NOMEM;

@@ -280,6 +280,34 @@ def test_overflowing_step_over_torch_distributed(gpu, tmp_path):
         assert np.array_equal(np.concatenate([r[key] for r in res])[order], want)
 
 
+def test_a_crowd_in_few_alignment_cells_needs_more_room_per_gpu(gpu, monkeypatch):
+    """With collisions on, splitters sit on the borders of cells at least four radius caps wide (here 4096 m for radii up
+    to 40 m).  20,000 bodies inside one such cell cannot be shared out over three shards:
+    refused with a message that names the way out, NBODY_DIST_HEADROOM, with which the run equals one engine's."""
+    rng = np.random.default_rng(21)
+    n = 20000
+    pos = 2048.0 + rng.uniform(-900.0, 900.0, (n, 3)); vel = rng.normal(0, 1e-2, (n, 3))     # inside the cell [0, 4096)^3
+    mass = np.abs(rng.normal(1e4, 5e3, n)) + 1.0; rad = rng.uniform(0.5, 40.0, n)
+    kw = dict(mode="tree", precision="f64", theta=0.6, dt=200.0, collisions=True)
+    monkeypatch.delenv("NBODY_DIST_HEADROOM", raising=False)
+    with Engine(devices=[0, 0, 0], distributed=True, **kw) as e:
+        e.upload(pos, vel, mass); e.set_radius(rad)
+        with pytest.raises(EngineError, match="NBODY_DIST_HEADROOM"):
+            e.step(1)
+    with Engine(exact_sums=True, **kw) as one:
+        one.upload(pos, vel, mass); one.set_radius(rad)
+        one.step(2)
+        want, wst = one.download(), one.stats()
+    monkeypatch.setenv("NBODY_DIST_HEADROOM", "3")
+    with Engine(devices=[0, 0, 0], distributed=True, **kw) as e:
+        e.upload(pos, vel, mass); e.set_radius(rad)
+        e.step(2)
+        got, gst = e.download(), e.stats()
+    assert gst.merges == wst.merges > 0 and gst.n_alive == wst.n_alive
+    for a, w in zip(got, want):
+        assert np.array_equal(a, w)
+
+
 def test_new_splitters_during_a_run_change_nothing_but_the_owners(gpu):
     """Splitters are chosen anew whenever a rank holds too many bodies (forced here before every step): bodies change
     owner wholesale, the trajectories stay those of one engine."""
