@@ -429,7 +429,8 @@ def test_distributed_tree_behind_one_engine_handle(gpu, precision, n, devices):
         e.step(2)
         p, v, m, ids = e.download()
         st = e.stats()
-        for call in (e.accel, e.tree_nodes, e.step_timed, lambda: e.time_force_kernel(1)):
+        acc, alive = e.accel()
+        for call in (e.tree_nodes, e.step_timed, lambda: e.time_force_kernel(1)):
             with pytest.raises(EngineError, match="distributed = 1|num_devices"):
                 call()
     assert st.n == n and st.n_alive == n and st.steps == 4
@@ -440,7 +441,15 @@ def test_distributed_tree_behind_one_engine_handle(gpu, precision, n, devices):
         one.upload(b.pos, b.vel, b.mass)
         one.step(2)
         ke1, pe1, mom1 = one.energy()              # (the exact pair sum at these sizes; the distributed run sums over accepted nodes)
+        one.step(2)
+        acc1, alive1 = one.accel()
     assert abs(ke - ke1) <= 1e-6 * ke1 and abs(pe - pe1) <= 5e-3 * abs(pe1)
+    # nbe_accel: every GPU's accelerations of its own bodies, in upload order
+    assert np.array_equal(alive, alive1) and alive.all()
+    if precision == "mixed":
+        assert np.abs(acc - acc1).max() <= 1e-6 * np.abs(acc1).max()
+    else:
+        assert np.array_equal(acc, acc1)
 
 
 @pytest.mark.parametrize("precision,devices", [("f32", [0, 0, 0]), ("mixed", [0, 0])])
