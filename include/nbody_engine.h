@@ -153,7 +153,8 @@ const char *nbe_last_error(void);
 /* Replaces the body slice built by makebodies (physics.go:16-73) / overwriteBodies (main.go:243-248):
  * n bodies as host structure-of-arrays, positions and velocities as xyzxyz...  `id` may be NULL
  * (then id = index, as physics.go:37,69 assign).  All bodies start alive.
- * Limits: 2^31-1 bodies in direct mode, 2^26 in tree mode (NBE_E_UNSUPPORTED beyond); masses must be >= 0. */
+ * Limits: 2^31-1 bodies in direct mode, 2^26 in tree mode (NBE_E_UNSUPPORTED beyond; with distributed = 1 that is the limit
+ * of one GPU's share, not of the run: 2^28 bodies have run as eight shares); masses must be >= 0. */
 int nbe_upload(nbe_engine *e, size_t n, const double *pos_xyz, const double *vel_xyz, const double *mass,
                const uint64_t *id);
 

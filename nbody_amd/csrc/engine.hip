@@ -182,7 +182,8 @@ extern "C" int nbe_upload(nbe_engine* e, size_t n, const double* pos, const doub
     if (!e) { nbe_set_error("engine is NULL"); return NBE_E_INVALID; }
     if (n > 0 && (!pos || !vel || !mass)) { nbe_set_error("nbe_upload: NULL array"); return NBE_E_INVALID; }
     if (n > 0x7fffffffull) { nbe_set_error("at most 2^31-1 bodies"); return NBE_E_UNSUPPORTED; }
-    if (e->cfg.mode == NBE_MODE_TREE && n > (1ull << 26)) { nbe_set_error("tree mode supports at most 2^26 bodies"); return NBE_E_UNSUPPORTED; }
+    // (with distributed = 1 no GPU holds all bodies: the limit is 2^26 per GPU there, checked by nbe_dist_upload)
+    if (e->cfg.mode == NBE_MODE_TREE && n > (1ull << 26) && !multi_is_distributed(e)) { nbe_set_error("tree mode supports at most 2^26 bodies"); return NBE_E_UNSUPPORTED; }
     for (size_t i = 0; i < n; i++)
         if (!(mass[i] >= 0.0)) { nbe_set_error("mass[%zu] is negative or NaN", i); return NBE_E_INVALID; }
     if (e->multi) return multi_upload(e, n, pos, vel, mass, id);
