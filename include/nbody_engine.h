@@ -199,10 +199,11 @@ int nbe_energy(nbe_engine *e, double *kinetic, double *potential, double momentu
 /* ---- sharded stepping (one engine per GPU, every engine holds all n bodies as sources) ----
  * The reference's only data-parallel strategy is to give each of 4 goroutines a contiguous quarter of the
  * bodies against a shared read-only tree (main.go:134-149); a shard is that quarter.
- *   nbe_set_shard(first, count)   targets [first, first+count) in device order belong to this engine (choose `first`
- *                                 as a multiple of 256: tree mode then matches a one-engine run bit for bit in every
- *                                 precision; otherwise NBE_PREC_MIXED, whose fp32 partial sums are flushed per
- *                                 wavefront of 64 or 128 consecutive bodies, differs in the last bits)
+ *   nbe_set_shard(first, count)   targets [first, first+count) in device order belong to this engine.  Tree mode with
+ *                                 the per-body test matches a one-engine run bit for bit in every precision wherever
+ *                                 the ranges begin (NBE_PREC_MIXED cuts a body's fp32 partial sums at nodes picked by
+ *                                 their records, not by its wavefront); NBE_WALK_PER_WAVE decides by aligned groups
+ *                                 of 128 bodies, so there choose `first` as a multiple of 128
  *   nbe_shard_sort                optional, tree mode: the part of the sort that reads positions only (keys, radix
  *                                 passes), so that it can run while the velocities of the other engines still arrive
  *   nbe_shard_prepare             tree mode: sort by Morton key, reorder state, build the tree (replicated)
@@ -240,8 +241,8 @@ int nbe_device_state(nbe_engine *e, nbe_device_state_t *out);
  *     moves these records (all-to-all), and nbe_dist_assemble lays out the rank's own fragments, the imported ones and
  *     the spanning cells as one pre-order node array.  The walk kernel then runs on it unchanged (nbe_dist_advance):
  *     every body visits exactly the nodes it visits in the one-engine tree, in the same order, so fp32 and fp64 runs
- *     equal a one-engine run with cell_sums = NBE_SUMS_EXACT bit for bit (NBE_PREC_MIXED to rounding: its partial sums
- *     are flushed by wavefront, and the wavefronts hold other bodies).
+ *     equal a one-engine run with cell_sums = NBE_SUMS_EXACT bit for bit, and so do NBE_PREC_MIXED runs: a body's fp32
+ *     partial sums join its fp64 totals after accepted nodes that are picked by their records alone.
  *     (Bodies that share all 63 key bits, i.e. lie in the same 3 cm cell of the reference's bound, are ordered by their
  *     upload index on one engine and by their run-wide index here, in runs of up to 64 such bodies, so they too are
  *     summed in one order everywhere; a longer run keeps the order in which its bodies reached the rank, and results

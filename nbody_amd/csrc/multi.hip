@@ -161,9 +161,9 @@ nbe_engine* multi_first(nbe_engine* e) { return e->multi->subs[0]; }
 
 static void ranges(size_t n, size_t parts, std::vector<uint64_t>* first, std::vector<uint64_t>* count)
 {
-    // Ranges start at multiples of 256 bodies, so that a wavefront of the tree walk holds the same 64 bodies as in a
-    // one-GPU run: mixed precision folds its fp32 partial sums into the fp64 totals every 64 node visits of the
-    // wavefront, and only then do the roundings fall where they fall on one GPU.
+    // Ranges start at multiples of 256 bodies, so that a wavefront of the tree walk holds the same bodies as in a
+    // one-GPU run: the per-wave criterion (NBE_WALK_PER_WAVE) decides for aligned groups of 128 bodies.  (The per-body
+    // walk gives a body the same bits whichever bodies share its wavefront, in every precision.)
     size_t per = (n + parts - 1) / parts;
     per = (per + 255) / 256 * 256;
     first->assign(parts, 0);

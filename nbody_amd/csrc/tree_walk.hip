@@ -169,6 +169,17 @@ __device__ __forceinline__ bool node_opens(const RawD& nd, double r2, double the
     return open;
 }
 
+// Mixed precision: where a body's fp32 partial sums join its fp64 totals.  After the term of every node that the body
+// takes and whose record hashes to 0 in six bits: one node in 64, picked by what the node is (its centre), not by
+// where it lies in an array or by what the wavefront has visited so far.  A body's sums are then a function of its own
+// list of accepted nodes alone, so its result has the same bits whichever bodies share its wavefront: one or two bodies
+// per lane, any shard boundary, a rank of the distributed tree.  (A count of the wavefront's visits, the earlier rule,
+// cut the sums where the neighbours' walks happened to stand.)  Scalar: the record is in scalar registers.
+__device__ __forceinline__ bool folds_here(const RawF& nd) { return (((nd.x ^ nd.y ^ nd.z) * 0x9E3779B1u) >> 26) == 0u; }
+__device__ __forceinline__ bool folds_here(const RawD&) { return false; }     // (fp64 records are never walked in mixed precision)
+
+template <bool V> struct Flag { static constexpr bool value = V; };
+
 #ifndef WALK_BLOCK
 #define WALK_BLOCK 256
 #endif
@@ -309,7 +320,7 @@ __global__ __launch_bounds__(WALK_BLOCK) void walk_kernel(
     R seed = (walked || !EVENTS) ? floor2v : FAR;
     int next_wake = 0x7fffffff, sp = 0, ends = 0;
     unsigned count = 0;
-    int it = 0;
+    [[maybe_unused]] int it = 0;                  // (visits of the wave: read by the WALK_VISIT_STATS build only)
     // The cursor and the node under it live in scalar registers: one scalar load per visit.  A visit is a chain of
     // dependent steps (load, distance, test, vote, next cursor), so the next node is requested as soon as the vote
     // is in and the force arithmetic of the current node runs while that load is in flight; the record behind the
@@ -318,7 +329,7 @@ __global__ __launch_bounds__(WALK_BLOCK) void walk_kernel(
     // four SIMDs, and the extra loads and selects cost more than the latency they hid.)
     int cur = 0;
     // One visit: consumes the record that `here` delivers, requests the successor into `there`.
-    auto visit = [&](auto& here, auto& there) -> bool {
+    auto visit = [&](auto& here, auto& there, auto look_for_end) -> bool {
         const auto nd = arrived(here);
         const int skip = nd.skip;
         // (the compare must not move up in front of the wait for the record: on the way out of the loop it would share
@@ -351,7 +362,8 @@ __global__ __launch_bounds__(WALK_BLOCK) void walk_kernel(
         there = request_raw(nodes, next, r2);      // the force arithmetic below runs while this is in flight
         const R mass = as_real(nd.m);
         bool counted = false;
-        if (COUNT) counted = active && !open && r2 < FAR_TEST && (dx != (R)0 || dy != (R)0 || dz != (R)0);
+        // (cur < total: mixed precision may visit the record behind the last node, which is no interaction)
+        if (COUNT) counted = active && !open && r2 < FAR_TEST && (dx != (R)0 || dy != (R)0 || dz != (R)0) && (!BLOCKED || cur < total);
         const bool take = active && !open;
         if (!EVENTS && take) my_skip = skip;
         if (EVENTS && opening != 0) {
@@ -390,27 +402,35 @@ __global__ __launch_bounds__(WALK_BLOCK) void walk_kernel(
             if (use) phi += (A)(rinv * mass);
         }
         ++it;
-        if constexpr (BLOCKED) if ((it & 63) == 0) {
-            // fp32 partial sums join the fp64 totals every 64 visits.  The totals live in LDS, not in registers: as
-            // registers the compiler gave them new ones in this rarely taken branch and copied them back on every
-            // visit (six 64-bit moves, +18 % time).
-            tot[0][threadIdx.x] += (A)fx; tot[1][threadIdx.x] += (A)fy; tot[2][threadIdx.x] += (A)fz;
-            fx = 0; fy = 0; fz = 0;
-        }
         cur = next;
-        if constexpr (!BLOCKED) return next < total;
-        // (mixed precision: with the wait behind the loop the compiler copies the record registers around the flush of
-        // the partial sums while a request is in flight, which the build's check of the assembly rejects)
-        if (next < total) return true;
-        settle(there);
-        return false;
+        if constexpr (!BLOCKED) return next < total; else {
+        // Mixed precision.
+        if (__builtin_expect(folds_here(nd), 0)) {
+            // The fp32 partial sums of the bodies that take this node join their fp64 totals (folds_here).  The totals
+            // live in LDS, not in registers: as registers the compiler gave them new ones in this rarely taken branch
+            // and copied them back on every visit (six 64-bit moves, +18 % time).
+            // (selects, not a branch on `take`: the compiler joins a per-lane condition with the node's into one mask
+            // and then sets and restores the execution mask in every visit, +19 % time)
+            tot[0][threadIdx.x] += take ? (A)fx : (A)0; tot[1][threadIdx.x] += take ? (A)fy : (A)0; tot[2][threadIdx.x] += take ? (A)fz : (A)0;
+            fx = take ? (R)0 : fx; fy = take ? (R)0 : fy; fz = take ? (R)0 : fz;
+        }
+        // The end of the walk is looked for in every second visit only (the fold test took the place of a test of the
+        // visit count that the compiler had put into every second visit).  The visit in between may then fall on the
+        // record behind the last node: massless, never opened, its successor is itself; folding there changes no total.
+        // (the wait on the way out of the visit: with the wait behind the loop the compiler copies the record registers
+        // around the fold while a request is in flight, which the build's check of the assembly rejects)
+        if constexpr (decltype(look_for_end)::value) {
+            if (next >= total) { settle(there); return false; }
+        }
+        return true;
+        }
     };
     R none = 0;
     auto slot_a = request_raw(nodes, 0, none);
     decltype(slot_a) slot_b;
     for (;;) {                                    // two record slots used in turn, so nothing is copied
-        if (!visit(slot_a, slot_b)) break;
-        if (!visit(slot_b, slot_a)) break;
+        if (!visit(slot_a, slot_b, Flag<!BLOCKED>{})) break;
+        if (!visit(slot_b, slot_a, Flag<true>{})) break;
     }
     // The record requested last is never read.  It still has to land before its registers may serve anything else:
     // waiting here, with both slots as operands, keeps them reserved on the way out of the loop.
@@ -583,7 +603,7 @@ __global__ __launch_bounds__(WALK_BLOCK) void walk_group_kernel(
 // (a body that sits out carries +infinity as its floor under r^2, so nothing in the visit is per body but the
 // arithmetic itself); with the per-body tests and selects of the earlier visit, two bodies per lane were slower
 // (2.57 against 2.08 ms at 1M bodies).
-// A = double (mixed precision): the fp32 partial sums of both bodies join fp64 totals every 64 visits, as in walk_kernel;
+// A = double (mixed precision): the fp32 partial sums of a body join its fp64 totals where walk_kernel's do (folds_here);
 // the totals live in LDS, and positions are read from the fp32 mirror while the fp64 state is integrated.
 template <typename A, int OUT, bool COUNT>
 __global__ __launch_bounds__(WALK_BLOCK) void walk_pair_kernel(
@@ -636,13 +656,12 @@ __global__ __launch_bounds__(WALK_BLOCK) void walk_pair_kernel(
 #pragma unroll
         for (int k = 0; k < 6; k++) tot[k][threadIdx.x] = 0;
     }
-    int it = 0;
     // Everything the epilogue needs from the kernel arguments is fetched here, ahead of the loop: a scalar load that
     // the compiler places at the loop's exit could be given the registers of the node request that is still in flight
     asm volatile("" :: "s"(G), "s"(dt), "s"(acc_out), "s"(interactions));
     unsigned count = 0;
     int cur = 0;
-    auto visit = [&](auto& here, auto& there) -> bool {
+    auto visit = [&](auto& here, auto& there, auto look_for_end) -> bool {
         RawF nd;
         if constexpr (BLOCKED) nd = arrived_behind(here, px, py, pz); else nd = arrived(here);
         const int skip = nd.skip;
@@ -672,8 +691,8 @@ __global__ __launch_bounds__(WALK_BLOCK) void walk_pair_kernel(
         const float mass = as_real(nd.m);
         bool u0 = false, u1 = false;
         if (COUNT) {
-            u0 = !open0 && r2.x < (float)INFINITY && (dx.x != 0.0f || dy.x != 0.0f || dz.x != 0.0f);
-            u1 = !open1 && r2.y < (float)INFINITY && (dx.y != 0.0f || dy.y != 0.0f || dz.y != 0.0f);
+            u0 = !open0 && r2.x < (float)INFINITY && (dx.x != 0.0f || dy.x != 0.0f || dz.x != 0.0f) && (!BLOCKED || cur < total);
+            u1 = !open1 && r2.y < (float)INFINITY && (dx.y != 0.0f || dy.y != 0.0f || dz.y != 0.0f) && (!BLOCKED || cur < total);
         }
         if (opening != 0) {
             // the cursor descends: the bodies that accept the cell sleep until the cursor reaches its end
@@ -709,25 +728,33 @@ __global__ __launch_bounds__(WALK_BLOCK) void walk_pair_kernel(
             phi[0] += u0 ? (A)pm.x : (A)0;
             phi[1] += u1 ? (A)pm.y : (A)0;
         }
-        if constexpr (BLOCKED) if ((++it & 63) == 0) {
-            tot[0][threadIdx.x] += (A)fx.x; tot[1][threadIdx.x] += (A)fy.x; tot[2][threadIdx.x] += (A)fz.x;
-            tot[3][threadIdx.x] += (A)fx.y; tot[4][threadIdx.x] += (A)fy.y; tot[5][threadIdx.x] += (A)fz.y;
-            fx = R2{0, 0}; fy = R2{0, 0}; fz = R2{0, 0};
-        }
         cur = next;
-        if constexpr (!BLOCKED) return next < total;
-        // (mixed precision waits on its way out of the visit, as walk_kernel does: with the wait behind the loop the two
-        // ways out have to agree on the registers of both slots, and the compiler copies one while it is in flight)
-        if (next < total) return true;
-        settle_plain(there);
-        return false;
+        if constexpr (!BLOCKED) return next < total; else {
+        // mixed precision: the fold and the end of the walk as in walk_kernel
+        if (__builtin_expect(folds_here(nd), 0)) {
+            // (a body takes the node iff its distance is still finite here: asleep or opening, it carries +infinity;
+            // selects, as in walk_kernel)
+            const bool take0 = r2.x != (float)INFINITY, take1 = r2.y != (float)INFINITY;
+            tot[0][threadIdx.x] += take0 ? (A)fx.x : (A)0; tot[1][threadIdx.x] += take0 ? (A)fy.x : (A)0; tot[2][threadIdx.x] += take0 ? (A)fz.x : (A)0;
+            tot[3][threadIdx.x] += take1 ? (A)fx.y : (A)0; tot[4][threadIdx.x] += take1 ? (A)fy.y : (A)0; tot[5][threadIdx.x] += take1 ? (A)fz.y : (A)0;
+            fx = R2{take0 ? 0.0f : fx.x, take1 ? 0.0f : fx.y};
+            fy = R2{take0 ? 0.0f : fy.x, take1 ? 0.0f : fy.y};
+            fz = R2{take0 ? 0.0f : fz.x, take1 ? 0.0f : fz.y};
+        }
+        // (the wait on the way out of the visit, as in walk_kernel: with the wait behind the loop the two ways out have
+        // to agree on the registers of both slots, and the compiler copies one while it is in flight)
+        if constexpr (decltype(look_for_end)::value) {
+            if (next >= total) { settle_plain(there); return false; }
+        }
+        return true;
+        }
     };
     float none = 0;
     auto slot_a = request_raw(nodes, 0, none);
     decltype(slot_a) slot_b;
     for (;;) {
-        if (!visit(slot_a, slot_b)) break;
-        if (!visit(slot_b, slot_a)) break;
+        if (!visit(slot_a, slot_b, Flag<!BLOCKED>{})) break;
+        if (!visit(slot_b, slot_a, Flag<true>{})) break;
     }
     // The record requested last is never read, but has to land before its registers are reused.
     if constexpr (!BLOCKED) settle(slot_a, slot_b);
@@ -873,13 +900,12 @@ static int launch_walk(nbe_engine* e, const void* src, uint64_t t0, uint64_t t1,
         // fp32 visits: two bodies per lane where there are enough bodies to fill the GPU several times over with 128-body waves
         // (measured, pair against one body per lane: 1M bodies 1.83 / 1.78 ms, 2M 3.46 / 3.49, 3M 4.89 / 5.16, 4M 6.53 /
         // 7.35, 8M 13.1 / 15.5, 16M 26.3 / 31.8: one million bodies are exactly one fill, and the slowest wave then sets
-        // the time).  fp32 sums are the same bits either way, so the launch's own size decides; mixed precision rounds by
-        // wavefront (its fp32 partial sums join the fp64 totals every 64 visits of the wavefront), so there the size of the
-        // scene decides, which every shard of a scene shares.  NBODY_WALK_BODIES_PER_LANE=1 or 2 forces the choice (tests).
+        // the time).  The sums are the same bits either way, also in mixed precision (folds_here), so the launch's own size
+        // decides.  NBODY_WALK_BODIES_PER_LANE=1 or 2 forces the choice (tests).
         const int forced = e->walk_bodies_per_lane;
-        const size_t deciding = __is_same(A, float) ? nt : (size_t)e->n;
+        const size_t deciding = nt;
         // (the instrumented pass in mixed precision stays with one body per lane: the compiler rejects that variant of
-        // the pair kernel, "illegal VGPR to SGPR copy"; its sums then differ from the step's by the rounding of the blocks)
+        // the pair kernel, "illegal VGPR to SGPR copy")
         // (mixed precision changes over at 1M bodies: its one-body kernel still tests every lane's sit-out index in every
         // visit, 17 vector instructions against 12, so two bodies per lane win earlier: two 512k-body galaxies 2.07 against
         // 2.13 ms)

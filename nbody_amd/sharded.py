@@ -20,9 +20,9 @@ except Exception:  # pragma: no cover - torch is part of the image
 
 def shard_range(n, rank, world, align=256):
     """Contiguous range of ceil(n/world) targets per rank, rounded up to a multiple of 256 (the last ranks may get
-    fewer or none).  Ranges that start at multiples of 256 give the wavefronts of the tree walk the same 64 bodies as
-    a one-GPU run, which mixed precision needs to round as one GPU does (its fp32 partial sums join the fp64 totals
-    every 64 node visits of the wavefront)."""
+    fewer or none).  Ranges that start at multiples of 256 give the wavefronts of the tree walk the same bodies as a
+    one-GPU run, which the per-wave criterion needs to decide as one GPU does (it opens cells for aligned groups of 128
+    bodies); the per-body walk gives every body the same bits wherever the ranges begin, in every precision."""
     per = (n + world - 1) // world
     per = (per + align - 1) // align * align
     first = min(rank * per, n)

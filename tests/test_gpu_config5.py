@@ -49,3 +49,23 @@ def test_two_8m_body_galaxies_mixed_precision_100_steps(gpu):
     assert abs((e1 - e0) / e0) <= 2e-3, abs((e1 - e0) / e0)
     pscale = (b.mass * np.linalg.norm(b.vel, axis=1)).sum()
     assert np.linalg.norm(p1 - p0) / pscale <= 1e-5, np.linalg.norm(p1 - p0) / pscale
+
+
+def test_two_8m_body_galaxies_on_the_distributed_tree_equal_one_engine_bit_for_bit(gpu):
+    """The same scene and precision with every body on one of eight ranks only (eight GPUs' worth behind one handle, on
+    this GPU): after three steps the state equals that of one engine that sums its cells exactly, bit for bit, all
+    16,777,216 bodies.  Mixed precision cuts a body's fp32 partial sums at nodes picked by their records, so the bodies
+    that happen to share its wavefront on a rank do not change its result."""
+    b = physics.galaxy_pair(1 << 23, seed=1)
+    n = len(b)
+    out = []
+    for kw in (dict(exact_sums=True), dict(devices=[0] * 8, distributed=True)):
+        with Engine(mode="tree", precision="mixed", theta=0.5, eps=1.0, **kw) as e:
+            e.upload(b.pos, b.vel, b.mass)
+            e.step(3)
+            p, v, m, ids = e.download()
+            assert e.stats().n_alive == n
+        o = np.argsort(ids, kind="stable")
+        out.append((ids[o], p[o], v[o], m[o]))
+    for a, w in zip(out[1], out[0]):
+        assert np.array_equal(a, w)

@@ -408,9 +408,8 @@ def test_tree_body_limit():
 
 @pytest.mark.parametrize("precision", ["f32", "mixed"])
 def test_shards_walking_two_bodies_per_lane_equal_one_engine(gpu, monkeypatch, precision):
-    """The walk with two bodies per lane (large scenes; forced here) on three shards behind one handle: ranges start at
-    multiples of 256 bodies, so a wavefront holds the same 128 bodies as on one engine and mixed precision, which rounds
-    by wavefront, equals the one-engine run bit for bit too."""
+    """The walk with two bodies per lane (large scenes; forced here) on three shards behind one handle: the one-engine
+    run bit for bit, also in mixed precision."""
     monkeypatch.setenv("NBODY_WALK_BODIES_PER_LANE", "2")
     b = physics.plummer(30011, seed=4, a=2e3)
     with Engine(mode="tree", precision=precision, theta=0.6, eps=1.0) as one:
@@ -420,6 +419,32 @@ def test_shards_walking_two_bodies_per_lane_equal_one_engine(gpu, monkeypatch, p
     with Engine(mode="tree", precision=precision, theta=0.6, eps=1.0, devices=[0, 0, 0]) as e:
         e.upload(b.pos, b.vel, b.mass)
         e.step(4)
+        got = e.download()
+    for a, w in zip(got, want):
+        assert np.array_equal(a, w)
+
+
+@pytest.mark.parametrize("precision", ["mixed", "f32", "f64"])
+@pytest.mark.parametrize("knob", ["1", "2"])
+def test_ranges_that_begin_anywhere_equal_one_engine(gpu, monkeypatch, precision, knob):
+    """nbe_shard_advance_range over ranges that begin at odd places (7, 1000, 4099 ...), so that every wavefront holds
+    other bodies than in the one-engine run: the same bits in every precision, with either walk kernel.  (Mixed
+    precision cuts a body's fp32 partial sums at nodes picked by their records, not by the wavefront's visits.)"""
+    monkeypatch.setenv("NBODY_WALK_BODIES_PER_LANE", knob)
+    n = 9001
+    b = physics.plummer(n, seed=6, a=2e3)
+    with Engine(mode="tree", precision=precision, theta=0.6, eps=0.5) as one:
+        one.upload(b.pos, b.vel, b.mass)
+        one.step(3)
+        want = one.download()
+    cuts = [0, 7, 1000, 4099, 4100, 8193, n]
+    with Engine(mode="tree", precision=precision, theta=0.6, eps=0.5) as e:
+        e.upload(b.pos, b.vel, b.mass)
+        for _ in range(3):
+            e.shard_prepare()
+            for a, z in zip(cuts[:-1], cuts[1:]):
+                e.shard_advance_range(a, z - a)
+            e.shard_commit()
         got = e.download()
     for a, w in zip(got, want):
         assert np.array_equal(a, w)

@@ -408,11 +408,11 @@ def test_every_lane_walking_alone_gives_the_bits_of_the_shared_cursor(gpu, monke
 
 
 @pytest.mark.parametrize("n", [2, 65, 129, 1000, 8193, 50001, 300000])
-def test_mixed_walk_with_two_bodies_per_lane_agrees_with_one_body_per_lane(gpu, monkeypatch, n):
-    """Mixed precision has the same two kernels.  Its fp32 partial sums join the fp64 totals every 64 visits of the
-    wavefront, and a wavefront of 128 bodies visits other nodes than one of 64, so the two round differently: the
-    accelerations agree to 2e-6 of each body's acceleration (fp32 rounding of a block sum is 6e-8 per term), the same
-    bodies survive, and both stay within the fp32 tolerances against the CPU restatement (median 1e-6, p99.9 1e-3)."""
+def test_mixed_walk_with_two_bodies_per_lane_equals_one_body_per_lane(gpu, monkeypatch, n):
+    """Mixed precision has the same two kernels.  A body's fp32 partial sums join its fp64 totals after every accepted
+    node whose record hashes to zero in six bits: a rule about the body's own list of accepted nodes, not about the
+    wavefront around it, so a wavefront of 128 bodies and one of 64 give every body the same bits (stepped states and
+    accelerations), and both stay within the fp32 tolerances against the CPU restatement elsewhere in this file."""
     b = physics.plummer(n, seed=n % 5, a=2e3)
     pos = b.pos.copy()
     if n > 10:
@@ -427,12 +427,5 @@ def test_mixed_walk_with_two_bodies_per_lane_agrees_with_one_body_per_lane(gpu, 
             p, v, m, ids = e.download()
             acc, alive = e.accel()            # (the instrumented pass always walks one body per lane)
             res.append((p, v, m, ids, acc, alive))
-    p1, v1, m1, id1, acc1, al1 = res[0]
-    p2, v2, m2, id2, acc2, al2 = res[1]
-    assert np.array_equal(id1, id2) and np.array_equal(m1, m2) and np.array_equal(al1, al2)
-    dv = np.linalg.norm(v1 - v2, axis=1)
-    # three kicks of dt = 3600 s: the velocity difference is dt times the difference of the accelerations
-    amag = np.linalg.norm(acc1[al1.astype(bool)], axis=1) if al1.dtype != bool else np.linalg.norm(acc1[al1], axis=1)
-    scale = 3 * 3600.0 * np.maximum(np.median(amag), 1e-300)
-    assert dv.max() <= 2e-5 * scale * max(1.0, amag.max() / np.median(amag)), (dv.max(), scale)
-    assert np.abs(p1 - p2).max() <= 1e-6 * np.abs(p1).max()
+    for a, c in zip(res[0], res[1]):
+        assert np.array_equal(a, c, equal_nan=True)
