@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Times the tree walk's kernel variants against each other (NBODY_WALK_BODIES_PER_LANE = 1 / 2) and checks that they
-agree: fp32 bit for bit, mixed precision to the rounding of its blocked sums.
+agree: fp32 bit for bit, mixed precision too.
 usage: python3 profiles/walk_variants.py [plummer_f32_sizes_in_2^20 ...]   (then the two-galaxy scene in mixed precision)"""
 import os
 import sys
