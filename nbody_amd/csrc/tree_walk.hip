@@ -180,6 +180,31 @@ __device__ __forceinline__ bool folds_here(const RawD&) { return false; }     //
 
 template <bool V> struct Flag { static constexpr bool value = V; };
 
+#ifdef WALK_TIMELINE
+// Measurement build (make timeline; profiles/walk_timeline.py): every wavefront of walk_kernel and walk_pair_kernel
+// leaves when it began and ended (constant 100 MHz clock) and where it ran, for a picture of how a launch fills and
+// drains the GPU.  Not part of the product build.
+#define WALK_TIMELINE_WAVES (1 << 18)
+__device__ unsigned long long walk_timeline[WALK_TIMELINE_WAVES][4];
+extern "C" int nbe_debug_walk_timeline(unsigned long long* out, size_t waves)
+{
+    if (waves > WALK_TIMELINE_WAVES) waves = WALK_TIMELINE_WAVES;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(walk_timeline), waves * 4 * sizeof(unsigned long long)) == hipSuccess ? 0 : 1;
+}
+__device__ __forceinline__ void timeline_note(unsigned wave_index, unsigned long long began)
+{
+    if ((threadIdx.x & 63) == 0 && wave_index < WALK_TIMELINE_WAVES) {
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        walk_timeline[wave_index][0] = began;
+        walk_timeline[wave_index][1] = wall_clock64();
+        walk_timeline[wave_index][2] = ((unsigned long long)xcc << 32) | hw;
+        walk_timeline[wave_index][3] = 0;
+    }
+}
+#endif
+
 #ifndef WALK_BLOCK
 #define WALK_BLOCK 256
 #endif
@@ -261,8 +286,8 @@ __device__ __forceinline__ unsigned walk_workgroup(unsigned xcd_shift)
 // the cursor passes over the subtree, the descend target stored in the record so that the request for the next node
 // stays one select away) gave the same bits at 2.14 ms against 1.89 ms (2.43 ms with the compiler's own loads, which it
 // turns into vector loads): the loop's records are waited for where the visit's are requested a whole visit ahead.
-template <typename R, typename A, typename NodeT, int OUT, bool COUNT, bool SOFT>
-__global__ __launch_bounds__(WALK_BLOCK) void walk_kernel(
+template <typename R, typename A, typename NodeT, int OUT, bool COUNT, bool SOFT, int WB>
+__global__ __launch_bounds__(WB) void walk_kernel(
     const NodeT* __restrict__ nodes, const int* __restrict__ counters, const typename V4<R>::type* __restrict__ posm,
     int t0, int t1, R theta, R floor2, A G, A dt, typename V4<A>::type* __restrict__ acc_out,
     const typename V4<A>::type* __restrict__ pos_in, const typename V4<A>::type* __restrict__ vel_in,
@@ -277,7 +302,10 @@ __global__ __launch_bounds__(WALK_BLOCK) void walk_kernel(
     const int total = counters[1];
     const int tend = t1 < na ? t1 : na;
     const unsigned wg = walk_workgroup(xcd_shift);
-    const int i = t0 + (int)wg * WALK_BLOCK + threadIdx.x;
+#ifdef WALK_TIMELINE
+    const unsigned long long began = wall_clock64();
+#endif
+    const int i = t0 + (int)wg * WB + threadIdx.x;
     if (OUT == OUT_FUSED) {
         // bodies past n_alive (removed by the bound check) move to the next buffer unchanged
         if (i >= tend && i < t1) {
@@ -292,7 +320,7 @@ __global__ __launch_bounds__(WALK_BLOCK) void walk_kernel(
     R px = 0, py = 0, pz = 0, fx = 0, fy = 0, fz = 0;
     if (valid) { const R4 p = posm[i]; px = p.x; py = p.y; pz = p.z; }
     A ax = 0, ay = 0, az = 0, phi = 0;
-    __shared__ A tot[BLOCKED ? 3 : 1][BLOCKED ? WALK_BLOCK : 1];
+    __shared__ A tot[BLOCKED ? 3 : 1][BLOCKED ? WB : 1];
     if constexpr (BLOCKED) { tot[0][threadIdx.x] = 0; tot[1][threadIdx.x] = 0; tot[2][threadIdx.x] = 0; }
     // tail_orig (NBE_QUIRK_DROP_TAIL): bodies whose upload index is tail_limit or more are not walked, like the
     // last n mod 4 bodies of main.go:134-148; they sit out the whole traversal and are integrated with zero force
@@ -437,6 +465,10 @@ __global__ __launch_bounds__(WALK_BLOCK) void walk_kernel(
     if constexpr (!BLOCKED) settle(slot_a, slot_b);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // nothing is in flight here; states it on every path out of the loop
 
+#ifdef WALK_TIMELINE
+    // (the visit count is not noted: kept alive past the loop it makes the compiler copy a record that is in flight)
+    timeline_note(wg * (WB / 64) + (threadIdx.x >> 6), began);
+#endif
     if (COUNT && (threadIdx.x & 63) == 0 && interactions) {
         atomicAdd(interactions, (unsigned long long)count);
 #ifdef WALK_VISIT_STATS
@@ -605,8 +637,8 @@ __global__ __launch_bounds__(WALK_BLOCK) void walk_group_kernel(
 // (2.57 against 2.08 ms at 1M bodies).
 // A = double (mixed precision): the fp32 partial sums of a body join its fp64 totals where walk_kernel's do (folds_here);
 // the totals live in LDS, and positions are read from the fp32 mirror while the fp64 state is integrated.
-template <typename A, int OUT, bool COUNT>
-__global__ __launch_bounds__(WALK_BLOCK) void walk_pair_kernel(
+template <typename A, int OUT, bool COUNT, int WB>
+__global__ __launch_bounds__(WB) void walk_pair_kernel(
     const NodeF* __restrict__ nodes, const int* __restrict__ counters, const float4* __restrict__ posm, int t0, int t1,
     float floor2, A G, A dt, typename V4<A>::type* __restrict__ acc_out, const typename V4<A>::type* __restrict__ pos_in,
     const typename V4<A>::type* __restrict__ vel_in, typename V4<A>::type* __restrict__ pos_out,
@@ -621,9 +653,12 @@ __global__ __launch_bounds__(WALK_BLOCK) void walk_pair_kernel(
     const int total = counters[1];
     const int tend = t1 < na ? t1 : na;
     const unsigned wg = walk_workgroup(xcd_shift);     // same XCD-aware placement as walk_kernel
+#ifdef WALK_TIMELINE
+    const unsigned long long began = wall_clock64();
+#endif
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int idx[2];
-    idx[0] = t0 + (int)wg * (2 * WALK_BLOCK) + wave * 128 + lane;
+    idx[0] = t0 + (int)wg * (2 * WB) + wave * 128 + lane;
     idx[1] = idx[0] + 64;
     bool valid[2];
 #pragma unroll
@@ -651,7 +686,7 @@ __global__ __launch_bounds__(WALK_BLOCK) void walk_pair_kernel(
     int next_wake = 0x7fffffff, sp = 0, ends = 0;
     R2 fx = {0, 0}, fy = {0, 0}, fz = {0, 0};
     A phi[2] = {0, 0};
-    __shared__ A tot[BLOCKED ? 6 : 1][BLOCKED ? WALK_BLOCK : 1];
+    __shared__ A tot[BLOCKED ? 6 : 1][BLOCKED ? WB : 1];
     if constexpr (BLOCKED) {
 #pragma unroll
         for (int k = 0; k < 6; k++) tot[k][threadIdx.x] = 0;
@@ -760,6 +795,9 @@ __global__ __launch_bounds__(WALK_BLOCK) void walk_pair_kernel(
     if constexpr (!BLOCKED) settle(slot_a, slot_b);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
+#ifdef WALK_TIMELINE
+    timeline_note(wg * (WB / 64) + wave, began);
+#endif
     if (COUNT && lane == 0 && interactions) atomicAdd(interactions, (unsigned long long)count);
     const float fxs[2] = {fx.x, fx.y}, fys[2] = {fy.x, fy.y}, fzs[2] = {fz.x, fz.y};
 #pragma unroll
@@ -778,7 +816,7 @@ __global__ __launch_bounds__(WALK_BLOCK) void walk_pair_kernel(
 }
 
 #define WALK_LAUNCH(...)                                                                                     \
-    hipLaunchKernelGGL((soft ? walk_kernel<R, A, NodeT, __VA_ARGS__, true> : walk_kernel<R, A, NodeT, __VA_ARGS__, false>),
+    hipLaunchKernelGGL((soft ? walk_kernel<R, A, NodeT, __VA_ARGS__, true, WB> : walk_kernel<R, A, NodeT, __VA_ARGS__, false, WB>),
 
 // ---- yardstick: every body walks alone ----------------------------------------------------------------------------------
 // The classic traversal: one lane, one body, one cursor per lane, node records through vector loads at up to 64
@@ -861,7 +899,18 @@ static int launch_walk(nbe_engine* e, const void* src, uint64_t t0, uint64_t t1,
     // 25.6 ms against 1.97 / 3.49 / 6.60 / 25.6 with chunks of 64; a rank's 2.1M bodies of a 16M-body tree 3.77 ms against
     // 3.62 with chunks of 16 to 64; so chunks serve launches that cover a part of a scene: ranks and shards)
     const bool part = e->dist || nt < (size_t)e->n;
-    const unsigned xcd_shift = e->walk_xcd_shift >= 0 ? (unsigned)e->walk_xcd_shift : (part ? 5u : 0u);
+    // Workgroups of walk_kernel and walk_pair_kernel.  fp32: one wavefront each.  Wave slots are handed out by the
+    // workgroup, and the wavefronts of a workgroup of four end at different times (lifetimes vary by 12-25 %), so slots
+    // wait for their siblings: 7,500 of 8,192 slots were busy in the steady state of a 16M-body launch
+    // (profiles/walk_timeline.py).  Measured on one box with 64 / 128 / 256 / 512 threads: 1M bodies 1.695 / 1.730 /
+    // 1.726 / 1.740 ms, 4M 6.14 / 6.30 / 6.28 / 6.40, 16M 24.90 / 25.61 / 25.69 / 26.44.  fp64 is level (3.20 ms at 1M
+    // all round), and mixed precision, whose totals live in LDS, is slower with small workgroups (1M: 1.91 / 1.88 / 1.83 /
+    // 1.89), so those two keep 256.
+    constexpr int WB = __is_same(A, float) ? 64 : WALK_BLOCK;
+    // (chunks are counted in groups of 256 bodies whatever the workgroup's size)
+    const unsigned wb_shift = WB == 64 ? 2u : 0u;
+    const unsigned xcd_shift = e->walk_xcd_shift >= 0 ? (e->walk_xcd_shift > 0 ? (unsigned)e->walk_xcd_shift + wb_shift : 0u)
+                                                      : (part ? 5u + wb_shift : 0u);
     if (group) {
         dim3 ggrid(cdiv((size_t)(t1 - (t0 & ~127ull)), 2 * WALK_BLOCK));
 #define GROUP_LAUNCH(...)                                                                                    \
@@ -916,9 +965,9 @@ static int launch_walk(nbe_engine* e, const void* src, uint64_t t0, uint64_t t1,
         const size_t least = __is_same(A, float) ? (e->dist ? 3u * (1u << 19) : 2u * (1u << 20)) : (1u << 20);
         const bool pair = (forced == 2 || (forced != 1 && deciding >= least)) && !(count && !__is_same(A, float));
         if (pair) {
-            dim3 pgrid(xcd_grid(cdiv(nt, 2 * WALK_BLOCK), xcd_shift));
+            dim3 pgrid(xcd_grid(cdiv(nt, 2 * WB), xcd_shift));
 #define PAIR_LAUNCH(...)                                                                                                       \
-    hipLaunchKernelGGL((walk_pair_kernel<A, __VA_ARGS__>), pgrid, dim3(WALK_BLOCK), 0, e->stream, (const NodeF*)e->tw.nodes,   \
+    hipLaunchKernelGGL((walk_pair_kernel<A, __VA_ARGS__, WB>), pgrid, dim3(WB), 0, e->stream, (const NodeF*)e->tw.nodes,   \
                        e->tw.counters, (const float4*)src, (int)t0, (int)t1, floor2, G, dt, (A4*)e->acc, pos_in, vel_in,       \
                        pos_out, vel_out, mirror_out, e->tw.d_interactions, tail_orig, tail_limit, xcd_shift)
             if (fused) {
@@ -936,18 +985,18 @@ static int launch_walk(nbe_engine* e, const void* src, uint64_t t0, uint64_t t1,
             return NBE_OK;
         }
     }
-    dim3 grid(xcd_grid(cdiv(nt, WALK_BLOCK), xcd_shift));
+    dim3 grid(xcd_grid(cdiv(nt, WB), xcd_shift));
     if (fused) {
-        WALK_LAUNCH(OUT_FUSED, false) grid, dim3(WALK_BLOCK), 0, e->stream, (const NodeT*)e->tw.nodes,
+        WALK_LAUNCH(OUT_FUSED, false) grid, dim3(WB), 0, e->stream, (const NodeT*)e->tw.nodes,
                            e->tw.counters, (const R4*)src, (int)t0, (int)t1, (R)e->cfg.theta, floor2, G, dt, (A4*)e->acc,
                            pos_in, vel_in, pos_out, vel_out, mirror_out, e->tw.d_interactions, tail_orig, tail_limit, xcd_shift);
     } else if (count) {
         NBE_HIP(hipMemsetAsync(e->tw.d_interactions, 0, 8 * sizeof(unsigned long long), e->stream));
-        WALK_LAUNCH(OUT_ACC, true) grid, dim3(WALK_BLOCK), 0, e->stream, (const NodeT*)e->tw.nodes,
+        WALK_LAUNCH(OUT_ACC, true) grid, dim3(WB), 0, e->stream, (const NodeT*)e->tw.nodes,
                            e->tw.counters, (const R4*)src, (int)t0, (int)t1, (R)e->cfg.theta, floor2, G, dt, (A4*)e->acc,
                            pos_in, vel_in, pos_out, vel_out, mirror_out, e->tw.d_interactions, tail_orig, tail_limit, xcd_shift);
     } else {
-        WALK_LAUNCH(OUT_ACC, false) grid, dim3(WALK_BLOCK), 0, e->stream, (const NodeT*)e->tw.nodes,
+        WALK_LAUNCH(OUT_ACC, false) grid, dim3(WB), 0, e->stream, (const NodeT*)e->tw.nodes,
                            e->tw.counters, (const R4*)src, (int)t0, (int)t1, (R)e->cfg.theta, floor2, G, dt, (A4*)e->acc,
                            pos_in, vel_in, pos_out, vel_out, mirror_out, e->tw.d_interactions, tail_orig, tail_limit, xcd_shift);
     }
