@@ -179,6 +179,7 @@ __device__ __forceinline__ bool folds_here(const RawF& nd) { return (((nd.x ^ nd
 __device__ __forceinline__ bool folds_here(const RawD&) { return false; }     // (fp64 records are never walked in mixed precision)
 
 template <bool V> struct Flag { static constexpr bool value = V; };
+template <int V> struct Size { static constexpr int value = V; };
 
 #ifdef WALK_TIMELINE
 // Measurement build (make timeline; profiles/walk_timeline.py): every wavefront of walk_kernel and walk_pair_kernel
@@ -903,18 +904,6 @@ static int launch_walk(nbe_engine* e, const void* src, uint64_t t0, uint64_t t1,
     // 25.6 ms against 1.97 / 3.49 / 6.60 / 25.6 with chunks of 64; a rank's 2.1M bodies of a 16M-body tree 3.77 ms against
     // 3.62 with chunks of 16 to 64; so chunks serve launches that cover a part of a scene: ranks and shards)
     const bool part = e->dist || nt < (size_t)e->n;
-    // Workgroups of walk_kernel and walk_pair_kernel.  fp32: one wavefront each.  Wave slots are handed out by the
-    // workgroup, and the wavefronts of a workgroup of four end at different times (lifetimes vary by 12-25 %), so slots
-    // wait for their siblings: 7,500 of 8,192 slots were busy in the steady state of a 16M-body launch
-    // (profiles/walk_timeline.py).  Measured on one box with 64 / 128 / 256 / 512 threads: 1M bodies 1.695 / 1.730 /
-    // 1.726 / 1.740 ms, 4M 6.14 / 6.30 / 6.28 / 6.40, 16M 24.90 / 25.61 / 25.69 / 26.44.  fp64 is level (3.20 ms at 1M
-    // all round), and mixed precision, whose totals live in LDS, is slower with small workgroups (1M: 1.91 / 1.88 / 1.83 /
-    // 1.89), so those two keep 256.
-    constexpr int WB = __is_same(A, float) ? 64 : WALK_BLOCK;
-    // (chunks are counted in groups of 256 bodies whatever the workgroup's size)
-    const unsigned wb_shift = WB == 64 ? 2u : 0u;
-    const unsigned xcd_shift = e->walk_xcd_shift >= 0 ? (e->walk_xcd_shift > 0 ? (unsigned)e->walk_xcd_shift + wb_shift : 0u)
-                                                      : (part ? 5u + wb_shift : 0u);
     if (group) {
         dim3 ggrid(cdiv((size_t)(t1 - (t0 & ~127ull)), 2 * WALK_BLOCK));
 #define GROUP_LAUNCH(...)                                                                                    \
@@ -949,63 +938,85 @@ static int launch_walk(nbe_engine* e, const void* src, uint64_t t0, uint64_t t1,
             return NBE_OK;
         }
     }
+    // fp32 visits: two bodies per lane where there are enough bodies to fill the GPU several times over with 128-body waves
+    // (measured, pair against one body per lane: 1M bodies 1.83 / 1.78 ms, 2M 3.46 / 3.49, 3M 4.89 / 5.16, 4M 6.53 /
+    // 7.35, 8M 13.1 / 15.5, 16M 26.3 / 31.8: one million bodies are exactly one fill, and the slowest wave then sets
+    // the time).  The sums are the same bits either way, also in mixed precision (folds_here), so the launch's own size
+    // decides.  NBODY_WALK_BODIES_PER_LANE=1 or 2 forces the choice (tests).
+    // (the instrumented pass in mixed precision stays with one body per lane: the compiler rejects that variant of
+    // the pair kernel, "illegal VGPR to SGPR copy")
+    // (mixed precision changes over at 1M bodies: its one-body kernel still tests every lane's sit-out index in every
+    // visit, 17 vector instructions against 12, so two bodies per lane win earlier: two 512k-body galaxies 2.07 against
+    // 2.13 ms)
+    // (fp32 changes over at 2M bodies of a launch: level with one body per lane there, ahead from then on.  A rank of the
+    // key-range-distributed tree walks the tree of the whole run, longer walks per body than a scene of its own size has:
+    // 2.1M targets of a 16M-body tree take 3.78 ms with two bodies per lane against 4.27 ms with one, so it changes over
+    // at 1.5M.)
+    bool pair = false;
     if constexpr (__is_same(R, float)) {
-        // fp32 visits: two bodies per lane where there are enough bodies to fill the GPU several times over with 128-body waves
-        // (measured, pair against one body per lane: 1M bodies 1.83 / 1.78 ms, 2M 3.46 / 3.49, 3M 4.89 / 5.16, 4M 6.53 /
-        // 7.35, 8M 13.1 / 15.5, 16M 26.3 / 31.8: one million bodies are exactly one fill, and the slowest wave then sets
-        // the time).  The sums are the same bits either way, also in mixed precision (folds_here), so the launch's own size
-        // decides.  NBODY_WALK_BODIES_PER_LANE=1 or 2 forces the choice (tests).
         const int forced = e->walk_bodies_per_lane;
-        const size_t deciding = nt;
-        // (the instrumented pass in mixed precision stays with one body per lane: the compiler rejects that variant of
-        // the pair kernel, "illegal VGPR to SGPR copy")
-        // (mixed precision changes over at 1M bodies: its one-body kernel still tests every lane's sit-out index in every
-        // visit, 17 vector instructions against 12, so two bodies per lane win earlier: two 512k-body galaxies 2.07 against
-        // 2.13 ms)
-        // (fp32 changes over at 2M bodies of a launch: level with one body per lane there, ahead from then on.  A rank of the
-        // key-range-distributed tree walks the tree of the whole run, longer walks per body than a scene of its own size has:
-        // 2.1M targets of a 16M-body tree take 3.78 ms with two bodies per lane against 4.27 ms with one, so it changes over
-        // at 1.5M.)
         const size_t least = __is_same(A, float) ? (e->dist ? 3u * (1u << 19) : 2u * (1u << 20)) : (1u << 20);
-        const bool pair = (forced == 2 || (forced != 1 && deciding >= least)) && !(count && !__is_same(A, float));
-        if (pair) {
-            dim3 pgrid(xcd_grid(cdiv(nt, 2 * WB), xcd_shift));
+        pair = (forced == 2 || (forced != 1 && nt >= least)) && !(count && !__is_same(A, float));
+    }
+    // Workgroups of one wavefront for launches that fill the GPU's 8,192 wave slots more than once.  Slots are handed out
+    // by the workgroup, and the wavefronts of a workgroup of four end at different times (lifetimes vary by 12-25 %), so
+    // slots wait for their siblings: 7,500 of 8,192 were busy in the steady state of a 16M-body launch, 8,030 are with
+    // workgroups of one (profiles/walk_timeline.py).  Measured on one box with 64 / 128 / 256 / 512 threads, fp32: 1M bodies
+    // 1.695 / 1.730 / 1.726 / 1.740 ms, 4M 6.14 / 6.30 / 6.28 / 6.40, 16M 24.90 / 25.61 / 25.69 / 26.44; mixed precision, 64
+    // against 256: one body per lane 1M 1.88 / 1.94, 2M 3.54 / 3.63; two per lane 2M level, two 8M-body galaxies 52.7 / 53.5,
+    // but 1M, which is one fill exactly, 1.85 / 1.80: nothing is refilled there, so such launches keep 256.  fp64 is level
+    // (3.20 ms at 1M all round) and keeps 256.
+    const size_t wavefronts = cdiv(nt, pair ? 128 : 64);
+    auto launch = [&](auto wb) -> int {
+        constexpr int WB = decltype(wb)::value;
+        // chunks of workgroups dealt to the XCDs in turn are counted in groups of 256 bodies whatever the workgroup's size
+        const unsigned wb_shift = WB == 64 ? 2u : 0u;
+        const unsigned xcd_shift = e->walk_xcd_shift >= 0 ? (e->walk_xcd_shift > 0 ? (unsigned)e->walk_xcd_shift + wb_shift : 0u)
+                                                          : (part ? 5u + wb_shift : 0u);
+        if constexpr (__is_same(R, float)) {
+            if (pair) {
+                dim3 pgrid(xcd_grid(cdiv(nt, 2 * WB), xcd_shift));
 #define PAIR_LAUNCH(...)                                                                                                       \
-    hipLaunchKernelGGL((walk_pair_kernel<A, __VA_ARGS__, WB>), pgrid, dim3(WB), 0, e->stream, (const NodeF*)e->tw.nodes,   \
+    hipLaunchKernelGGL((walk_pair_kernel<A, __VA_ARGS__, WB>), pgrid, dim3(WB), 0, e->stream, (const NodeF*)e->tw.nodes,       \
                        e->tw.counters, (const float4*)src, (int)t0, (int)t1, floor2, G, dt, (A4*)e->acc, pos_in, vel_in,       \
                        pos_out, vel_out, mirror_out, e->tw.d_interactions, tail_orig, tail_limit, xcd_shift)
-            if (fused) {
-                PAIR_LAUNCH(OUT_FUSED, false);
-            } else if (count) {
-                if constexpr (__is_same(A, float)) {
-                    NBE_HIP(hipMemsetAsync(e->tw.d_interactions, 0, 8 * sizeof(unsigned long long), e->stream));
-                    PAIR_LAUNCH(OUT_ACC, true);
+                if (fused) {
+                    PAIR_LAUNCH(OUT_FUSED, false);
+                } else if (count) {
+                    if constexpr (__is_same(A, float)) {
+                        NBE_HIP(hipMemsetAsync(e->tw.d_interactions, 0, 8 * sizeof(unsigned long long), e->stream));
+                        PAIR_LAUNCH(OUT_ACC, true);
+                    }
+                } else {
+                    PAIR_LAUNCH(OUT_ACC, false);
                 }
-            } else {
-                PAIR_LAUNCH(OUT_ACC, false);
-            }
 #undef PAIR_LAUNCH
-            NBE_HIP(hipGetLastError());
-            return NBE_OK;
+                NBE_HIP(hipGetLastError());
+                return NBE_OK;
+            }
         }
+        dim3 grid(xcd_grid(cdiv(nt, WB), xcd_shift));
+        if (fused) {
+            WALK_LAUNCH(OUT_FUSED, false) grid, dim3(WB), 0, e->stream, (const NodeT*)e->tw.nodes,
+                               e->tw.counters, (const R4*)src, (int)t0, (int)t1, (R)e->cfg.theta, floor2, G, dt, (A4*)e->acc,
+                               pos_in, vel_in, pos_out, vel_out, mirror_out, e->tw.d_interactions, tail_orig, tail_limit, xcd_shift);
+        } else if (count) {
+            NBE_HIP(hipMemsetAsync(e->tw.d_interactions, 0, 8 * sizeof(unsigned long long), e->stream));
+            WALK_LAUNCH(OUT_ACC, true) grid, dim3(WB), 0, e->stream, (const NodeT*)e->tw.nodes,
+                               e->tw.counters, (const R4*)src, (int)t0, (int)t1, (R)e->cfg.theta, floor2, G, dt, (A4*)e->acc,
+                               pos_in, vel_in, pos_out, vel_out, mirror_out, e->tw.d_interactions, tail_orig, tail_limit, xcd_shift);
+        } else {
+            WALK_LAUNCH(OUT_ACC, false) grid, dim3(WB), 0, e->stream, (const NodeT*)e->tw.nodes,
+                               e->tw.counters, (const R4*)src, (int)t0, (int)t1, (R)e->cfg.theta, floor2, G, dt, (A4*)e->acc,
+                               pos_in, vel_in, pos_out, vel_out, mirror_out, e->tw.d_interactions, tail_orig, tail_limit, xcd_shift);
+        }
+        NBE_HIP(hipGetLastError());
+        return NBE_OK;
+    };
+    if constexpr (__is_same(R, float)) {
+        if (wavefronts > 8192) return launch(Size<64>{});
     }
-    dim3 grid(xcd_grid(cdiv(nt, WB), xcd_shift));
-    if (fused) {
-        WALK_LAUNCH(OUT_FUSED, false) grid, dim3(WB), 0, e->stream, (const NodeT*)e->tw.nodes,
-                           e->tw.counters, (const R4*)src, (int)t0, (int)t1, (R)e->cfg.theta, floor2, G, dt, (A4*)e->acc,
-                           pos_in, vel_in, pos_out, vel_out, mirror_out, e->tw.d_interactions, tail_orig, tail_limit, xcd_shift);
-    } else if (count) {
-        NBE_HIP(hipMemsetAsync(e->tw.d_interactions, 0, 8 * sizeof(unsigned long long), e->stream));
-        WALK_LAUNCH(OUT_ACC, true) grid, dim3(WB), 0, e->stream, (const NodeT*)e->tw.nodes,
-                           e->tw.counters, (const R4*)src, (int)t0, (int)t1, (R)e->cfg.theta, floor2, G, dt, (A4*)e->acc,
-                           pos_in, vel_in, pos_out, vel_out, mirror_out, e->tw.d_interactions, tail_orig, tail_limit, xcd_shift);
-    } else {
-        WALK_LAUNCH(OUT_ACC, false) grid, dim3(WB), 0, e->stream, (const NodeT*)e->tw.nodes,
-                           e->tw.counters, (const R4*)src, (int)t0, (int)t1, (R)e->cfg.theta, floor2, G, dt, (A4*)e->acc,
-                           pos_in, vel_in, pos_out, vel_out, mirror_out, e->tw.d_interactions, tail_orig, tail_limit, xcd_shift);
-    }
-    NBE_HIP(hipGetLastError());
-    return NBE_OK;
+    return launch(Size<WALK_BLOCK>{});
 }
 
 // Forces on sorted targets [t0, t1) of buffer `src_buf` from the tree built over that buffer.  `count` (only
