@@ -1,7 +1,8 @@
 """A Plummer sphere of 2^17 bodies inside the reference's bound for thousands of steps on the distributed tree behind one
-handle (five ranks on this GPU) and on one engine, fp32: every bit of the state compared every 250 steps.
+handle (five ranks on this GPU) and on one engine, fp32 (or the precision named): every bit of the state compared every
+250 steps.
 
-usage: python3 profiles/soak_plummer.py [steps=2000] [ranks=5] [log2 bodies=17]"""
+usage: python3 profiles/soak_plummer.py [steps=2000] [ranks=5] [log2 bodies=17] [precision=f32]"""
 import os
 import sys
 import time
@@ -14,8 +15,9 @@ from nbody_amd import Engine, physics                                       # no
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
 ranks = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 log2n = int(sys.argv[3]) if len(sys.argv) > 3 else 17
+precision = sys.argv[4] if len(sys.argv) > 4 else "f32"
 b = physics.plummer(1 << log2n, seed=3)
-kw = dict(mode="tree", precision="f32", theta=0.6, dt=3600.0)
+kw = dict(mode="tree", precision=precision, theta=0.6, dt=3600.0)
 one = Engine(exact_sums=True, **kw)
 dist = Engine(devices=[0] * ranks, distributed=True, **kw)
 for e in (one, dist):
