@@ -246,8 +246,9 @@ __device__ __forceinline__ unsigned walk_workgroup(unsigned xcd_shift)
 // rate: about 58 issue cycles per visit against 78 cycles measured per visit and SIMD, so the vector ALU is busy
 // three quarters of the time; the scalar cache serves only 29 % of the node loads (L2 serves 97 % of the rest
 // after the XCD remap), and eight waves per SIMD hide most of that latency.  Consequently neither the workgroup
-// size (64 .. 1024 threads: 2.16 .. 2.31 ms) nor a second traversal per wave nor prefetching both successors of
-// a node helps, and every scalar instruction removed from the loop does (five fewer: -4 %).
+// size (64 .. 1024 threads: 2.16 .. 2.31 ms then; with today's shorter visit workgroups of one wavefront are worth 3 %
+// to launches that fill the GPU more than once, see launch_walk) nor a second traversal per wave nor prefetching both
+// successors of a node helps, and every scalar instruction removed from the loop does (five fewer: -4 %).
 // The visits are not equally useful: in 84 % nobody opens the node, in 5 % nobody takes it, and in 27 % at most 8
 // of the 64 lanes are awake (deep in the near field of a few bodies while the rest of the wave sits out).
 // Tried: handing subtrees that at most 16 lanes open to those lanes for private walks with vector loads after
