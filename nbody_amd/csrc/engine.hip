@@ -125,6 +125,10 @@ extern "C" int nbe_create(const nbe_config* cfg, nbe_engine** out)
         if (v >= 0 && v <= 12) e->walk_xcd_shift = (int)v;
     }
     if (const char* env = getenv("NBODY_WALK_PRIVATE")) e->walk_private = env[0] == '1';     // measurement knob, see walk_private_kernel
+    if (const char* env = getenv("NBODY_WALK_SPARSE")) {             // measurement knob: bodies per wavefront of small launches
+        const long v = strtol(env, nullptr, 10);
+        if (v >= 0 && v <= 6) e->walk_sparse = (int)v;
+    }
     int rc = use_device(e);
     if (rc == NBE_OK && hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking) != hipSuccess) {
         nbe_set_error("hipStreamCreate failed");

@@ -183,6 +183,7 @@ struct nbe_engine {
     int small_max = 0;              // tree mode: up to this many bodies take the single-workgroup sort and scans
     int walk_bodies_per_lane = 0;   // fp32 tree walk: 1 or 2 forces the kernel (test knob), 0 chooses by the number of targets
     int walk_xcd_shift = -1;        // NBODY_WALK_XCD_CHUNK_LOG2: -1 the engine's choice, 0 contiguous eighths, s chunks of 2^s groups of 256 bodies
+    int walk_sparse = -1;           // NBODY_WALK_SPARSE=s: 64 >> s bodies per wavefront of the one-body walk (-1: the engine's choice)
     bool walk_private = false;      // NBODY_WALK_PRIVATE=1: force passes without update take the one-body-one-cursor yardstick kernel (fp32)
     bool timing = false;            // record phase events during the next step
     bool have_counts = false;       // tw.counters hold the result of a build of this upload

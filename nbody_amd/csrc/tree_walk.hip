@@ -299,7 +299,7 @@ __global__ __launch_bounds__(WB) void walk_kernel(
     const typename V4<A>::type* __restrict__ pos_in, const typename V4<A>::type* __restrict__ vel_in,
     typename V4<A>::type* __restrict__ pos_out, typename V4<A>::type* __restrict__ vel_out,
     float4* __restrict__ mirror_out, unsigned long long* __restrict__ interactions,
-    const uint32_t* __restrict__ tail_orig, unsigned tail_limit, unsigned xcd_shift)
+    const uint32_t* __restrict__ tail_orig, unsigned tail_limit, unsigned xcd_shift, unsigned sparse)
 {
     using R4 = typename V4<R>::type;
     using A4 = typename V4<A>::type;
@@ -311,7 +311,10 @@ __global__ __launch_bounds__(WB) void walk_kernel(
 #ifdef WALK_TIMELINE
     const unsigned long long began = wall_clock64();
 #endif
-    const int i = t0 + (int)wg * WB + threadIdx.x;
+    // sparse = s > 0 (few targets, see launch_walk): only the first 64 >> s lanes of a wavefront hold a body, so that the
+    // targets spread over more wavefronts with shorter walks; the other lanes sit out like lanes past the last body
+    const int per_wave = 64 >> sparse, lane_in_wave = (int)(threadIdx.x & 63);
+    const int i = lane_in_wave < per_wave ? t0 + (int)((wg * (WB / 64) + (threadIdx.x >> 6)) * (unsigned)per_wave) + lane_in_wave : 0x7fffffff;
     if (OUT == OUT_FUSED) {
         // bodies past n_alive (removed by the bound check) move to the next buffer unchanged
         if (i >= tend && i < t1) {
@@ -967,7 +970,19 @@ static int launch_walk(nbe_engine* e, const void* src, uint64_t t0, uint64_t t1,
     // against 256: one body per lane 1M 1.88 / 1.94, 2M 3.54 / 3.63; two per lane 2M level, two 8M-body galaxies 52.7 / 53.5,
     // but 1M, which is one fill exactly, 1.85 / 1.80: nothing is refilled there, so such launches keep 256.  fp64 is level
     // (3.20 ms at 1M all round) and keeps 256.
-    const size_t wavefronts = cdiv(nt, pair ? 128 : 64);
+    // Few targets: a wavefront's walk is a chain of dependent visits (~130 ns each); with a wavefront or two per SIMD
+    // nothing hides it, and most of the 1,024 SIMDs have nothing to do.  Fewer bodies per wavefront (64 >> sparse) make
+    // more and shorter walks, the same bits for every body.  Measured, force kernel with 64 / 16 / 4 / 1 bodies per
+    // wavefront: the reference's default scene (1,002 bodies, theta 1) 34 / 21 / 19 / 14 us (step 98 -> 60 us), 4,096 bodies
+    // 238 / 190 / 173 / 163, 16,384 bodies 372 / 303 / 287 / 562, 65,536 bodies 488 / 427 / 745 / 2,080: best where the
+    // launch has 2,048 to 4,096 wavefronts (fp64, whose wavefronts are heavier, where it has 2,048), never beyond.
+    unsigned sparse = 0;
+    if (!pair) {
+        const size_t most = __is_same(R, double) ? 2048 : 4096;
+        while (sparse < 6 && cdiv(nt, 64u >> (sparse + 1)) <= most) sparse++;
+        if (e->walk_sparse >= 0) sparse = (unsigned)e->walk_sparse;             // NBODY_WALK_SPARSE
+    }
+    const size_t wavefronts = pair ? cdiv(nt, 128) : cdiv(nt, 64u >> sparse);
     auto launch = [&](auto wb) -> int {
         constexpr int WB = decltype(wb)::value;
         // chunks of workgroups dealt to the XCDs in turn are counted in groups of 256 bodies whatever the workgroup's size
@@ -996,20 +1011,20 @@ static int launch_walk(nbe_engine* e, const void* src, uint64_t t0, uint64_t t1,
                 return NBE_OK;
             }
         }
-        dim3 grid(xcd_grid(cdiv(nt, WB), xcd_shift));
+        dim3 grid(xcd_grid(cdiv(cdiv(nt, 64u >> sparse), WB / 64), xcd_shift));
         if (fused) {
             WALK_LAUNCH(OUT_FUSED, false) grid, dim3(WB), 0, e->stream, (const NodeT*)e->tw.nodes,
                                e->tw.counters, (const R4*)src, (int)t0, (int)t1, (R)e->cfg.theta, floor2, G, dt, (A4*)e->acc,
-                               pos_in, vel_in, pos_out, vel_out, mirror_out, e->tw.d_interactions, tail_orig, tail_limit, xcd_shift);
+                               pos_in, vel_in, pos_out, vel_out, mirror_out, e->tw.d_interactions, tail_orig, tail_limit, xcd_shift, sparse);
         } else if (count) {
             NBE_HIP(hipMemsetAsync(e->tw.d_interactions, 0, 8 * sizeof(unsigned long long), e->stream));
             WALK_LAUNCH(OUT_ACC, true) grid, dim3(WB), 0, e->stream, (const NodeT*)e->tw.nodes,
                                e->tw.counters, (const R4*)src, (int)t0, (int)t1, (R)e->cfg.theta, floor2, G, dt, (A4*)e->acc,
-                               pos_in, vel_in, pos_out, vel_out, mirror_out, e->tw.d_interactions, tail_orig, tail_limit, xcd_shift);
+                               pos_in, vel_in, pos_out, vel_out, mirror_out, e->tw.d_interactions, tail_orig, tail_limit, xcd_shift, sparse);
         } else {
             WALK_LAUNCH(OUT_ACC, false) grid, dim3(WB), 0, e->stream, (const NodeT*)e->tw.nodes,
                                e->tw.counters, (const R4*)src, (int)t0, (int)t1, (R)e->cfg.theta, floor2, G, dt, (A4*)e->acc,
-                               pos_in, vel_in, pos_out, vel_out, mirror_out, e->tw.d_interactions, tail_orig, tail_limit, xcd_shift);
+                               pos_in, vel_in, pos_out, vel_out, mirror_out, e->tw.d_interactions, tail_orig, tail_limit, xcd_shift, sparse);
         }
         NBE_HIP(hipGetLastError());
         return NBE_OK;
