@@ -193,6 +193,9 @@ int nbe_stats(nbe_engine *e, nbe_stats_t *stats);
  * drift checks.  Up to 262,144 bodies the potential is the exact fp64 pair sum; above that, tree mode sums it over
  * the nodes its walk accepts (same theta as the forces) and direct mode accepts up to 4,194,304 bodies.  In tree mode
  * "live" means inside the bound, as the coming step will see them (the call builds the tree, which that step reuses).
+ * In NBE_PREC_MIXED the tree's potential is summed, like its forces, over the fp32 copies of the positions: two bodies
+ * that coincide there (closer than fp32 resolves, millimetres at the reference's scale) add nothing, where the pair sum
+ * reads the fp64 positions and counts them.
  * No counterpart in the reference (its only validation is the rendered frames). */
 int nbe_energy(nbe_engine *e, double *kinetic, double *potential, double momentum[3]);
 
