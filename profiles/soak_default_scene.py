@@ -2,7 +2,7 @@
 step) for thousands of steps on the distributed tree behind one handle (three ranks on this GPU) and on one engine, fp64:
 survivors, merges and every bit of the state compared every 500 steps.
 
-usage: python3 profiles/soak_default_scene.py [steps=5000] [ranks=3]"""
+usage: python3 profiles/soak_default_scene.py [steps=5000] [ranks=3] [precision=f64]"""
 import os
 import sys
 import time
@@ -14,10 +14,11 @@ from nbody_amd import Engine, physics                                       # no
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 5000
 ranks = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+precision = sys.argv[3] if len(sys.argv) > 3 else "f64"
 b = physics.makebodies(1000, seed=1)
 n = len(b.mass)
 rad = np.full(n, 2.0); rad[:2] = 1.0
-kw = dict(mode="tree", precision="f64", theta=1.0, dt=3600.0, collisions=True)
+kw = dict(mode="tree", precision=precision, theta=1.0, dt=3600.0, collisions=True)
 one = Engine(exact_sums=True, **kw)
 dist = Engine(devices=[0] * ranks, distributed=True, **kw)
 for e in (one, dist):
