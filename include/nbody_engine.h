@@ -154,7 +154,9 @@ const char *nbe_last_error(void);
  * n bodies as host structure-of-arrays, positions and velocities as xyzxyz...  `id` may be NULL
  * (then id = index, as physics.go:37,69 assign).  All bodies start alive.
  * Limits: 2^31-1 bodies in direct mode, 2^26 in tree mode (NBE_E_UNSUPPORTED beyond; with distributed = 1 that is the limit
- * of one GPU's share, not of the run: 2^28 bodies have run as eight shares); masses must be >= 0. */
+ * of one GPU's share, not of the run: 2^28 bodies have run as eight shares); masses must be >= 0.
+ * With distributed = 1 every GPU gets room for a quarter more than an even share of the bodies; NBODY_DIST_HEADROOM in the
+ * environment (1.25 .. the number of GPUs, read here) gives more, for scenes that cannot be shared out evenly. */
 int nbe_upload(nbe_engine *e, size_t n, const double *pos_xyz, const double *vel_xyz, const double *mass,
                const uint64_t *id);
 
