@@ -429,3 +429,36 @@ def test_mixed_walk_with_two_bodies_per_lane_equals_one_body_per_lane(gpu, monke
             res.append((p, v, m, ids, acc, alive))
     for a, c in zip(res[0], res[1]):
         assert np.array_equal(a, c, equal_nan=True)
+
+
+@pytest.mark.parametrize("precision", ["f32", "mixed", "f64"])
+@pytest.mark.parametrize("n", [3, 1002, 5000, 70001])
+def test_fewer_bodies_per_wavefront_give_the_same_bits(gpu, monkeypatch, precision, n):
+    """Small launches walk with fewer than 64 bodies per wavefront (down to one), chosen by the launch's size;
+    NBODY_WALK_SPARSE=s forces 64 >> s.  Every body's interactions, their order and its sums are its own, so accelerations,
+    interaction counts and stepped states are the same bits for 64, 8 and 1 bodies per wavefront and for the engine's own
+    choice, with bodies outside the bound, coincident bodies and the reference's unwalked tail."""
+    b = physics.plummer(n, seed=n % 9, a=2e3)
+    pos = b.pos.copy()
+    if n > 10:
+        pos[3] = pos[7]
+        pos[5] = [4e4, 0, 0]
+    out = []
+    for knob in (None, "0", "3", "6"):
+        if knob is None:
+            monkeypatch.delenv("NBODY_WALK_SPARSE", raising=False)
+        else:
+            monkeypatch.setenv("NBODY_WALK_SPARSE", knob)
+        res = []
+        for kw in (dict(), dict(drop_tail=True, eps=1.5)):
+            with Engine(mode="tree", precision=precision, theta=0.7, **kw) as e:
+                e.upload(pos, b.vel, b.mass)
+                acc, alive = e.accel()
+                st = e.stats()
+                e.step(2)
+                res.append((acc, alive, np.array([st.interactions]), *e.download()))
+        out.append(res)
+    for other in out[1:]:
+        for ra, rb in zip(out[0], other):
+            for a, c in zip(ra, rb):
+                assert np.array_equal(a, c, equal_nan=True)
